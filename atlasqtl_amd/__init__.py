@@ -1,0 +1,13 @@
+"""atlasqtl_amd -- MI355X-native variational-inference hot path of atlasqtl.
+
+Public surface mirrors the reference package's exports for this path
+(NAMESPACE:3-10): atlasqtl, set_hyper, set_init; plus the operator-level
+coreDualLoop / coreDualMisLoop (R/RcppExports.R) backed by libatlasqtl_hip.so.
+"""
+from .api import atlasqtl  # noqa: F401
+from .core import VbRun, atlasqtl_global_local_core_, coreDualLoop, coreDualMisLoop  # noqa: F401
+from .hyper_init import set_hyper, set_init  # noqa: F401
+from .prepare import AtlasqtlError  # noqa: F401
+
+__all__ = ["atlasqtl", "set_hyper", "set_init", "coreDualLoop", "coreDualMisLoop", "atlasqtl_global_local_core_",
+           "VbRun", "AtlasqtlError"]

@@ -1,0 +1,105 @@
+"""ctypes binding of libatlasqtl_hip.so (the C ABI of include/atlasqtl_hip.h).
+
+The library is the product: there is no Python or CPU fallback.  If the shared
+object is missing, or no HIP device is visible when a compute entry is called,
+the error is raised loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libatlasqtl_hip.so")
+
+AQ_OK = 0
+AQ_VB_DONE = 0
+AQ_VB_NEED_ALLREDUCE_MAIN = 1
+AQ_VB_NEED_ALLREDUCE_ELBO = 2
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+
+
+class AqVbProblem(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("p", C.c_int32), ("q", C.c_int32), ("q_total", C.c_int32),
+        ("X", dp), ("Y", dp),
+        ("A2_inv", C.c_double), ("m0", C.c_double), ("nu", C.c_double), ("rho", C.c_double), ("t02", C.c_double),
+        ("eta", dp), ("kappa", dp), ("n0", dp),
+        ("gam_vb", dp), ("mu_beta_vb", dp), ("sig02_inv_vb", C.c_double), ("sig2_beta_vb", dp),
+        ("sig2_theta_vb", dp), ("tau_vb", dp), ("theta_vb", dp), ("zeta_vb", dp),
+        ("has_anneal", C.c_int32), ("anneal", C.c_double * 3), ("tol", C.c_double), ("maxit", C.c_int32),
+        ("thinned_elbo_eval", C.c_int32), ("debug", C.c_int32),
+        ("device", C.c_int32), ("world_size", C.c_int32),
+        ("ext_reduce_main", C.c_void_p), ("ext_reduce_elbo", C.c_void_p),
+    ]
+
+
+class AqVbStatus(C.Structure):
+    _fields_ = [
+        ("it", C.c_int32), ("converged", C.c_int32), ("lb_opt", C.c_double), ("diff_lb", C.c_double),
+        ("c", C.c_double), ("annealing", C.c_int32), ("n_elbo", C.c_int32), ("core_ms", C.c_double),
+        ("core_launches", C.c_int32), ("sig02_inv_vb", C.c_double), ("sig2_inv_vb", C.c_double),
+        ("lentz_iters", C.c_int32),
+    ]
+
+
+# every symbol include/atlasqtl_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "aq_last_error": (C.c_char_p, []),
+    "aq_version": (C.c_char_p, []),
+    "aq_device_count": (C.c_int, []),
+    "aq_core_dual_loop": (C.c_int, [dp, dp, dp, dp, dp, C.c_double, dp, dp, dp, dp, dp, dp, ip, C.c_int32, ip,
+                                    C.c_int32, C.c_double, C.c_int32, C.c_int32]),
+    "aq_core_dual_mis_loop": (C.c_int, [dp, C.POINTER(dp), dp, dp, dp, dp, C.c_double, dp, dp, dp, dp, dp, dp, ip,
+                                        C.c_int32, ip, C.c_int32, C.c_double, C.c_int32, C.c_int32]),
+    "aq_vb_reduce_len": (C.c_int64, [C.c_int32]),
+    "aq_vb_create": (C.c_int, [C.POINTER(AqVbProblem), C.POINTER(C.c_void_p)]),
+    "aq_vb_destroy": (None, [C.c_void_p]),
+    "aq_vb_advance": (C.c_int, [C.c_void_p]),
+    "aq_vb_reduce_ptr": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "aq_vb_run": (C.c_int, [C.c_void_p]),
+    "aq_vb_run_sweeps": (C.c_int, [C.c_void_p, C.c_int32]),
+    "aq_vb_get_status": (C.c_int, [C.c_void_p, C.POINTER(AqVbStatus)]),
+    "aq_vb_get_elbo_trace": (C.c_int32, [C.c_void_p, ip, dp, C.c_int32]),
+    "aq_vb_get_result": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
+    "aq_special_eval": (C.c_int, [C.c_int32, dp, dp, dp, C.c_int64]),
+    "aq_q_approx_vec": (C.c_int, [dp, dp, C.c_int64, ip]),
+}
+
+_lib = None
+
+
+class AtlasqtlHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libatlasqtl_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AtlasqtlHipError(f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; "
+                                   "g.build()' or make -C atlasqtl_amd/csrc). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != AQ_OK:
+        msg = lib().aq_last_error().decode("utf-8", "replace")
+        raise AtlasqtlHipError(f"{what}: [{rc}] {msg}" if what else f"[{rc}] {msg}")
+
+
+def as_dp(a):
+    return a.ctypes.data_as(dp)
+
+
+def as_ip(a):
+    return a.ctypes.data_as(ip)

@@ -1,0 +1,278 @@
+"""Host-side mirror of the reference's operator interface for the VB hot path.
+
+Same names, argument meaning and error behaviour as the reference's R functions,
+with the arithmetic done by libatlasqtl_hip.so on the GPU:
+
+  coreDualLoop(...) / coreDualMisLoop(...)     R/RcppExports.R:4-10  (in place, as the reference)
+  atlasqtl_global_local_core_(...)             R/atlasqtl_global_local_core.R:8-433
+
+One process drives one GPU.  With a torch.distributed process group the trait
+axis q is sharded over the ranks: each rank passes its own columns of Y and of
+the q-indexed hyper-parameters / initial values; the only exchange per sweep is
+one SUM all-reduce (RCCL over xGMI) of aq_vb_reduce_len(p) doubles, plus one of
+8 doubles on the sweeps where the ELBO is evaluated.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AqVbProblem, AqVbStatus, as_dp, as_ip, check, lib
+
+
+def _f64F(a, name, shape=None):
+    a = np.asarray(a)
+    if a.dtype != np.float64 or not a.flags.f_contiguous:
+        raise TypeError(f"{name} must be a float64 Fortran-ordered (R layout) array; it is updated in place")
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {shape}, got {a.shape}")
+    return a
+
+
+def _vec(a, name, n):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != (n,):
+        raise ValueError(f"{name} must have length {n}")
+    return a
+
+
+def coreDualLoop(cp_X, cp_Y_X, gam_vb, log_Phi_theta_plus_zeta, log_1_min_Phi_theta_plus_zeta, log_sig2_inv_vb,
+                 log_tau_vb, m1_beta, cp_betaX_X, mu_beta_vb, sig2_beta_vb, tau_vb, shuffled_ind, sample_q, c=1.0):
+    """R/RcppExports.R:4-6 -> src/coreLoop.cpp:38-86.  gam_vb, m1_beta, cp_betaX_X, mu_beta_vb are
+    modified in place (they must be float64 Fortran-ordered p x q arrays); returns None."""
+    gam_vb = _f64F(gam_vb, "gam_vb")
+    p, q = gam_vb.shape
+    cp_X = _f64F(np.asfortranarray(cp_X, dtype=np.float64), "cp_X", (p, p))
+    cp_Y_X = _f64F(np.asfortranarray(cp_Y_X, dtype=np.float64), "cp_Y_X", (q, p))
+    lP = _f64F(np.asfortranarray(log_Phi_theta_plus_zeta, dtype=np.float64), "log_Phi_theta_plus_zeta", (p, q))
+    l1 = _f64F(np.asfortranarray(log_1_min_Phi_theta_plus_zeta, dtype=np.float64), "log_1_min_Phi_theta_plus_zeta",
+               (p, q))
+    m1_beta = _f64F(m1_beta, "m1_beta", (p, q))
+    cp_betaX_X = _f64F(cp_betaX_X, "cp_betaX_X", (p, q))
+    mu_beta_vb = _f64F(mu_beta_vb, "mu_beta_vb", (p, q))
+    lt = _vec(log_tau_vb, "log_tau_vb", q)
+    s2 = _vec(sig2_beta_vb, "sig2_beta_vb", q)
+    tv = _vec(tau_vb, "tau_vb", q)
+    si = np.ascontiguousarray(shuffled_ind, dtype=np.int32)
+    sq = np.ascontiguousarray(sample_q, dtype=np.int32)
+    rc = lib().aq_core_dual_loop(as_dp(cp_X), as_dp(cp_Y_X), as_dp(gam_vb), as_dp(lP), as_dp(l1),
+                                 float(log_sig2_inv_vb), as_dp(lt), as_dp(m1_beta), as_dp(cp_betaX_X),
+                                 as_dp(mu_beta_vb), as_dp(s2), as_dp(tv), as_ip(si), len(si), as_ip(sq), len(sq),
+                                 float(c), p, q)
+    check(rc, "coreDualLoop")
+
+
+def coreDualMisLoop(cp_X, cp_X_rm, cp_Y_X, gam_vb, log_Phi_theta_plus_zeta, log_1_min_Phi_theta_plus_zeta,
+                    log_sig2_inv_vb, log_tau_vb, m1_beta, cp_betaX_X, mu_beta_vb, sig2_beta_vb, tau_vb, shuffled_ind,
+                    sample_q, c=1.0):
+    """R/RcppExports.R:8-10 -> src/coreLoop.cpp:91-138.  cp_X_rm: list of q (p x p) matrices;
+    sig2_beta_vb: p x q.  In place like coreDualLoop."""
+    gam_vb = _f64F(gam_vb, "gam_vb")
+    p, q = gam_vb.shape
+    if len(cp_X_rm) != q:
+        raise ValueError("cp_X_rm must be a list of q matrices")
+    cp_X = np.asfortranarray(cp_X, dtype=np.float64)
+    rms = [_f64F(np.asfortranarray(m, dtype=np.float64), "cp_X_rm[[k]]", (p, p)) for m in cp_X_rm]
+    arr = (_lib.dp * q)(*[as_dp(m) for m in rms])
+    cp_Y_X = np.asfortranarray(cp_Y_X, dtype=np.float64)
+    lP = np.asfortranarray(log_Phi_theta_plus_zeta, dtype=np.float64)
+    l1 = np.asfortranarray(log_1_min_Phi_theta_plus_zeta, dtype=np.float64)
+    m1_beta = _f64F(m1_beta, "m1_beta", (p, q))
+    cp_betaX_X = _f64F(cp_betaX_X, "cp_betaX_X", (p, q))
+    mu_beta_vb = _f64F(mu_beta_vb, "mu_beta_vb", (p, q))
+    s2 = _f64F(np.asfortranarray(sig2_beta_vb, dtype=np.float64), "sig2_beta_vb", (p, q))
+    lt = _vec(log_tau_vb, "log_tau_vb", q)
+    tv = _vec(tau_vb, "tau_vb", q)
+    si = np.ascontiguousarray(shuffled_ind, dtype=np.int32)
+    sq = np.ascontiguousarray(sample_q, dtype=np.int32)
+    rc = lib().aq_core_dual_mis_loop(as_dp(cp_X), arr, as_dp(cp_Y_X), as_dp(gam_vb), as_dp(lP), as_dp(l1),
+                                     float(log_sig2_inv_vb), as_dp(lt), as_dp(m1_beta), as_dp(cp_betaX_X),
+                                     as_dp(mu_beta_vb), as_dp(s2), as_dp(tv), as_ip(si), len(si), as_ip(sq), len(sq),
+                                     float(c), p, q)
+    check(rc, "coreDualMisLoop")
+
+
+class VbRun:
+    """A device-resident VB state (aq_vb_handle).  Keeps the host arrays alive while the
+    library copies them, drives the aq_vb_advance protocol and fetches results."""
+
+    def __init__(self, Y, X, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval=True, debug=True,
+                 device=0, q_total=None, process_group=None):
+        L = lib()
+        Y = np.asfortranarray(Y, dtype=np.float64)
+        X = np.asfortranarray(X, dtype=np.float64)
+        n, p = X.shape
+        if Y.shape[0] != n:
+            raise ValueError("X and Y must have the same number of samples.")
+        q = Y.shape[1]
+        self.n, self.p, self.q = n, p, q
+        self.q_total = int(q if q_total is None else q_total)
+        self.pg = process_group
+        self.world = 1
+        self._red = self._ered = None
+        ext_main = ext_elbo = None
+        if process_group is not None:
+            import torch
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+            dev = torch.device("cuda", device)
+            self._red = torch.zeros(int(L.aq_vb_reduce_len(p)), dtype=torch.float64, device=dev)
+            self._ered = torch.zeros(8, dtype=torch.float64, device=dev)
+            ext_main, ext_elbo = self._red.data_ptr(), self._ered.data_ptr()
+        pr = AqVbProblem()
+        pr.n, pr.p, pr.q, pr.q_total = n, p, q, self.q_total
+        keep = []
+
+        def vec(v, m, name):
+            a = np.asarray(v, dtype=np.float64)
+            a = np.full(m, float(a)) if a.ndim == 0 else np.ascontiguousarray(a)
+            if a.shape != (m,):
+                raise ValueError(f"{name} must have length {m}, got {a.shape}")
+            keep.append(a)
+            return as_dp(a)
+
+        def mat(v, shape, name):
+            a = np.asfortranarray(v, dtype=np.float64)
+            if a.shape != shape:
+                raise ValueError(f"{name} must have shape {shape}, got {a.shape}")
+            keep.append(a)
+            return as_dp(a)
+
+        keep += [X, Y]
+        pr.X, pr.Y = as_dp(X), as_dp(Y)
+        pr.A2_inv = float(list_hyper["A2_inv"]); pr.m0 = float(list_hyper["m0"])
+        pr.nu = float(list_hyper["nu"]); pr.rho = float(list_hyper["rho"]); pr.t02 = float(list_hyper["t02"])
+        pr.eta = vec(list_hyper["eta"], q, "eta"); pr.kappa = vec(list_hyper["kappa"], q, "kappa")
+        pr.n0 = vec(list_hyper["n0"], q, "n0")
+        pr.gam_vb = mat(list_init["gam_vb"], (p, q), "gam_vb")
+        pr.mu_beta_vb = mat(list_init["mu_beta_vb"], (p, q), "mu_beta_vb")
+        pr.sig02_inv_vb = float(list_init["sig02_inv_vb"])
+        pr.sig2_beta_vb = vec(list_init["sig2_beta_vb"], q, "sig2_beta_vb")
+        pr.sig2_theta_vb = vec(list_init["sig2_theta_vb"], p, "sig2_theta_vb")
+        pr.tau_vb = vec(list_init["tau_vb"], q, "tau_vb")
+        pr.theta_vb = vec(list_init["theta_vb"], p, "theta_vb")
+        pr.zeta_vb = vec(list_init["zeta_vb"], q, "zeta_vb")
+        pr.has_anneal = 0 if anneal is None else 1
+        if anneal is not None:
+            pr.anneal = (C.c_double * 3)(*[float(x) for x in anneal])
+        pr.tol = float(tol); pr.maxit = int(maxit)
+        pr.thinned_elbo_eval = 1 if thinned_elbo_eval else 0
+        pr.debug = 1 if debug else 0
+        pr.device = int(device); pr.world_size = int(self.world)
+        pr.ext_reduce_main = ext_main
+        pr.ext_reduce_elbo = ext_elbo
+        h = C.c_void_p()
+        check(L.aq_vb_create(C.byref(pr), C.byref(h)), "aq_vb_create")
+        self.h = h
+        self._keep = keep
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().aq_vb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _allreduce(self, which):
+        if self.pg is None:
+            return
+        import torch.distributed as dist
+        dist.all_reduce(self._red if which == 0 else self._ered, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def advance_until_done(self):
+        """aq_vb_advance loop; all-reduces the payloads across the process group."""
+        L = lib()
+        while True:
+            rc = L.aq_vb_advance(self.h)
+            if rc < 0:
+                check(-rc, "aq_vb_advance")
+            if rc == _lib.AQ_VB_DONE:
+                return
+            self._allreduce(0 if rc == _lib.AQ_VB_NEED_ALLREDUCE_MAIN else 1)
+
+    def run(self):
+        if self.pg is None:
+            check(lib().aq_vb_run(self.h), "aq_vb_run")
+        else:
+            self.advance_until_done()
+        return self
+
+    def run_sweeps(self, k):
+        """Run at most k further sweeps (single process only; bench.py's timed region)."""
+        check(lib().aq_vb_run_sweeps(self.h, int(k)), "aq_vb_run_sweeps")
+
+    def status(self):
+        st = AqVbStatus()
+        check(lib().aq_vb_get_status(self.h, C.byref(st)), "aq_vb_get_status")
+        return {f[0]: getattr(st, f[0]) for f in AqVbStatus._fields_}
+
+    def elbo_trace(self):
+        cap = 4096
+        its = np.zeros(cap, dtype=np.int32)
+        lbs = np.zeros(cap, dtype=np.float64)
+        n = lib().aq_vb_get_elbo_trace(self.h, as_ip(its), as_dp(lbs), cap)
+        return its[:n].copy(), lbs[:n].copy()
+
+    def result(self, full_output=False):
+        p, q = self.p, self.q
+        beta = np.zeros((p, q), order="F"); gam = np.zeros((p, q), order="F")
+        theta = np.zeros(p); zeta = np.zeros(q)
+        mu = np.zeros((p, q), order="F") if full_output else None
+        lam = np.zeros(p) if full_output else None
+        s2t = np.zeros(p) if full_output else None
+        tau = np.zeros(q) if full_output else None
+        s2b = np.zeros(q) if full_output else None
+        nul = C.cast(None, _lib.dp)
+        check(lib().aq_vb_get_result(self.h, as_dp(beta), as_dp(gam), as_dp(mu) if full_output else nul, as_dp(theta),
+                                     as_dp(zeta), as_dp(lam) if full_output else nul,
+                                     as_dp(s2t) if full_output else nul, as_dp(tau) if full_output else nul,
+                                     as_dp(s2b) if full_output else nul), "aq_vb_get_result")
+        out = dict(beta_vb=beta, gam_vb=gam, theta_vb=theta, zeta_vb=zeta)
+        if full_output:
+            out.update(mu_beta_vb=mu, lam2_inv_vb=lam, sig2_theta_vb=s2t, tau_vb=tau, sig2_beta_vb=s2b)
+        return out
+
+
+def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbose, list_hyper, list_init,
+                                checkpoint_path=None, trace_path=None, full_output=False, thinned_elbo_eval=True,
+                                debug=False, batch="y", device=0, process_group=None):
+    """R/atlasqtl_global_local_core.R:8-433 on the GPU.  Returns the reference's list
+    (:426-428): beta_vb, gam_vb, theta_vb, zeta_vb, n, p, q, anneal, converged, it, maxit,
+    tol, lb_opt, diff_lb (+ the variational parameters with full_output).
+
+    shr_fac_inv is the total number of traits (R/atlasqtl.R:218); with a process group each
+    rank passes its own trait columns and shr_fac_inv = q of the whole problem."""
+    if df != 1:
+        raise NotImplementedError("df != 1 is unreachable from atlasqtl() (df <- 1, R/atlasqtl.R:272)")
+    if batch != "y":
+        raise ValueError("Batch scheme not defined. Exit.")            # :231
+    if checkpoint_path is not None or trace_path is not None:
+        raise NotImplementedError("checkpoint_path / trace_path are outside the accelerated path")
+    run = VbRun(Y, X, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval, debug, device=device,
+                q_total=int(shr_fac_inv), process_group=process_group)
+    try:
+        run.run()
+        st = run.status()
+        if verbose != 0:
+            if st["converged"]:
+                print(f"Convergence obtained after {st['it']} iterations. \nOptimal marginal log-likelihood "
+                      f"variational lower bound (ELBO) = {st['lb_opt']}. \n")
+            else:
+                import warnings
+                warnings.warn("Maximal number of iterations reached before convergence. Exit.")   # :397
+        res = run.result(full_output=full_output)
+        its, lbs = run.elbo_trace()
+        res.update(n=run.n, p=run.p, q=run.q, anneal=anneal, converged=bool(st["converged"]), it=int(st["it"]),
+                   maxit=maxit, tol=tol, lb_opt=st["lb_opt"], diff_lb=st["diff_lb"])
+        if full_output:
+            res.update(sig02_inv_vb=st["sig02_inv_vb"], sig2_inv_vb=st["sig2_inv_vb"], elbo_trace=(its, lbs),
+                       core_ms=st["core_ms"], core_launches=st["core_launches"], lentz_iters=st["lentz_iters"])
+        return res
+    finally:
+        run.close()

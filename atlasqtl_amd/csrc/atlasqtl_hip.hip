@@ -1,0 +1,838 @@
+// atlasqtl_hip.hip -- host side of libatlasqtl_hip.so: the C ABI declared in
+// include/atlasqtl_hip.h, the device-resident VB state and the sweep sequencing that
+// replaces the reference's R-level loop (R/atlasqtl_global_local_core.R:125-386).
+// gfx950 only.  No CPU fallback: every entry fails loudly without a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/atlasqtl_hip.h"
+#include "aq_core_sweep.h"
+#include "aq_gram_loop.h"
+#include "aq_special.h"
+#include "aq_vec_kernels.h"
+
+// ------------------------------------------------------------------ errors ----
+static thread_local std::string g_err;
+static int aq_fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define AQ_HIP(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return aq_fail(AQ_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + \
+                                        std::to_string(__LINE__) + ")");                               \
+  } while (0)
+
+extern "C" const char *aq_last_error(void) { return g_err.c_str(); }
+extern "C" const char *aq_version(void) { return "atlasqtl_hip 0.1.0 (gfx950)"; }
+extern "C" int aq_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int aq_need_device(int device) {
+  int n = aq_device_count();
+  if (n <= 0)
+    return aq_fail(AQ_ERR_DEVICE, "no HIP device visible: libatlasqtl_hip has no CPU fallback (MI355X / gfx950 required)");
+  if (device < 0 || device >= n) return aq_fail(AQ_ERR_ARG, "device ordinal out of range");
+  AQ_HIP(hipSetDevice(device));
+  return AQ_OK;
+}
+
+// ------------------------------------------------- f64 MFMA D-layout probe ----
+// D = A(16x4) * B(4x16) with A[i][k] = (k==0 ? i : 0), B[0][j] = 1  =>  D[i][j] = i.
+// Reading reg 1 of lane 16 tells which row the (reg, lane>>4) pair maps to.
+__global__ void aq_k_probe_dlayout(double *out) {
+  int lane = threadIdx.x & 63;
+  double av = ((lane >> 4) == 0) ? (double)(lane & 15) : 0.0;
+  double bv = ((lane >> 4) == 0) ? 1.0 : 0.0;
+  aq_d4 acc = {0, 0, 0, 0};
+  acc = aq_mfma(av, bv, acc);
+  for (int r = 0; r < 4; r++) out[lane * 4 + r] = acc[r];
+}
+static int g_dmode = -1;
+static int aq_probe_dmode(int *dmode) {
+  if (g_dmode >= 0) {
+    *dmode = g_dmode;
+    return AQ_OK;
+  }
+  double *d;
+  AQ_HIP(hipMalloc(&d, 256 * sizeof(double)));
+  hipLaunchKernelGGL(aq_k_probe_dlayout, dim3(1), dim3(64), 0, 0, d);
+  double h[256];
+  AQ_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  AQ_HIP(hipFree(d));
+  // lane 16 (g = 1), reg 1: row = g + 4*reg = 5 (mode 0)  or  4*g + reg = 5 (mode 1)?  ambiguous -> use lane 16 reg 0
+  // lane 16, reg 0: mode 0 -> row 1, mode 1 -> row 4.
+  double v = h[16 * 4 + 0];
+  int mode;
+  if (v == 1.0) mode = 0;
+  else if (v == 4.0) mode = 1;
+  else return aq_fail(AQ_ERR_DEVICE, "unexpected v_mfma_f64_16x16x4 accumulator layout (probe value " + std::to_string(v) + ")");
+  // full check of the chosen map
+  for (int lane = 0; lane < 64; lane++)
+    for (int r = 0; r < 4; r++) {
+      int g = lane >> 4;
+      int row = mode ? 4 * g + r : 4 * r + g;
+      if (h[lane * 4 + r] != (double)row)
+        return aq_fail(AQ_ERR_DEVICE, "v_mfma_f64_16x16x4 accumulator layout does not match either known map");
+    }
+  g_dmode = mode;
+  *dmode = mode;
+  return AQ_OK;
+}
+
+// ----------------------------------------------------------------- helpers ----
+template <typename T>
+static int aq_dalloc(T **ptr, size_t count) {
+  AQ_HIP(hipMalloc((void **)ptr, count * sizeof(T)));
+  AQ_HIP(hipMemset(*ptr, 0, count * sizeof(T)));
+  return AQ_OK;
+}
+#define AQ_TRY(x)            \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_ != AQ_OK) return rc_; \
+  } while (0)
+
+static int aq_upload_padded(double *dst, const double *src, size_t n, size_t n_pad) {
+  AQ_HIP(hipMemset(dst, 0, n_pad * sizeof(double)));
+  AQ_HIP(hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+  return AQ_OK;
+}
+
+// ------------------------------------------------------------------ state ----
+struct aq_vb {
+  int n, p, q, q_total, p_pad, q_pad, n_pad, nb, ntile, NT, NW, dmode, device, world;
+  // hyper / control
+  double A2_inv, m0, nu, rho, t02, t02_inv, shr;
+  bool has_anneal;
+  double anneal[3];
+  std::vector<double> ladder;
+  double tol;
+  int maxit;
+  bool thinned, debug;
+  // device buffers
+  double2 *XA = nullptr, *XU = nullptr;
+  double *G = nullptr, *R = nullptr, *gam = nullptr, *mu = nullptr;
+  double *theta = nullptr, *sig2_theta = nullptr, *L = nullptr, *lam2_inv = nullptr, *Q = nullptr, *ppart = nullptr;
+  double *eta_h = nullptr, *kappa_h = nullptr, *n0 = nullptr, *nobs = nullptr;
+  double *zeta = nullptr, *tau = nullptr, *sig2b = nullptr, *log_tau = nullptr, *eta_vb = nullptr, *kappa_vb = nullptr;
+  double *coef = nullptr, *inv2s = nullptr, *cst = nullptr, *sums = nullptr, *rowA = nullptr, *rowGB = nullptr;
+  double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
+  int TT = 1;
+  bool pre_done = false;
+  double *red = nullptr, *ered = nullptr, *Hpart = nullptr;
+  bool own_red = false, own_ered = false;
+  AqScalars *sc = nullptr;
+  int pblk = 0, nHchunk = 0, rows_per_chunk = 0;
+  // host-side loop state (R/atlasqtl_global_local_core.R:73-97,121-123)
+  bool annealing = false;
+  double c = 1.0, c_s = 1.0, sig2_zeta = 0.0, vec_sum_log_det_zeta = 0.0;
+  int it_init = 1;
+  std::vector<double> times_conv_sched;
+  std::vector<int> batch_conv_sched;
+  int ind_batch_conv = 0, batch_conv = 1;
+  bool converged = false;
+  double lb_new = -std::numeric_limits<double>::infinity(), lb_old = -std::numeric_limits<double>::infinity();
+  int it = 0;
+  int phase = 0;   // 0 start, 1 after init reduce, 2 sweep part A next, 3 after main reduce, 4 after elbo reduce
+  bool has_missing = false;
+  std::vector<int> trace_it;
+  std::vector<double> trace_lb;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  double core_ms_acc = 0.0;
+  int core_launches = 0;
+  bool failed = false;
+};
+
+static void aq_free_all(aq_vb *s) {
+  if (!s) return;
+  hipSetDevice(s->device);
+  void *ptrs[] = {s->XA, s->XU, s->G, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
+                  s->eta_h, s->kappa_h, s->n0, s->nobs, s->zeta, s->tau, s->sig2b, s->log_tau, s->eta_vb, s->kappa_vb,
+                  s->coef, s->inv2s, s->cst, s->sums, s->rowA, s->rowGB, s->Aarr, s->Barr, s->colApart, s->Hpart, s->sc};
+  for (void *ptr : ptrs)
+    if (ptr) hipFree(ptr);
+  if (s->own_red && s->red) hipFree(s->red);
+  if (s->own_ered && s->ered) hipFree(s->ered);
+  for (auto &e : s->ev) {
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  delete s;
+}
+
+extern "C" int64_t aq_vb_reduce_len(int32_t p) { return (int64_t)((p + 15) / 16) * 16 + AQ_RED_EXTRA; }
+
+// get_annealing_ladder_, R/utils.R:108-146
+static std::vector<double> aq_ladder(const double anneal[3]) {
+  double k_m = 1.0 / anneal[1];
+  int m = (int)std::llround(anneal[2]);
+  std::vector<double> l(m);
+  int type = (int)std::llround(anneal[0]);
+  if (type == 1) {
+    double delta = std::pow(k_m, 1.0 / (1 - m)) - 1;
+    for (int i = 0; i < m; i++) l[i] = std::pow(1 + delta, 1.0 - (double)(m - i));
+  } else if (type == 2) {
+    double delta = (1 / k_m - 1) / (m - 1);
+    for (int i = 0; i < m; i++) l[i] = 1.0 / (1 + delta * ((double)(m - i) - 1));
+  } else {
+    double delta = (1 - k_m) / (m - 1);
+    for (int i = 0; i < m; i++) l[i] = k_m + delta * (double)i;
+  }
+  return l;
+}
+
+static int aq_launch_core(aq_vb *s, int mode, double c) {
+  AqCoreArgs a;
+  a.XA = s->XA; a.XU = s->XU; a.G = s->G; a.R = s->R; a.gam = s->gam; a.mu = s->mu;
+  a.Aarr = s->Aarr; a.Barr = s->Barr; a.coef = s->coef; a.inv2s = s->inv2s; a.cst = s->cst; a.sig2b = s->sig2b;
+  a.sums = s->sums; a.rowGB = s->rowGB;
+  a.c = c;
+  a.p = s->p; a.q = s->q; a.p_pad = s->p_pad; a.q_pad = s->q_pad; a.n_pad = s->n_pad; a.nb = s->nb; a.ntile = s->ntile;
+  a.dmode = s->dmode; a.mode = mode;
+  dim3 grid((s->ntile + s->TT - 1) / s->TT), block(s->NW * 64);
+  hipEvent_t e0, e1;
+  AQ_HIP(hipEventCreate(&e0));
+  AQ_HIP(hipEventCreate(&e1));
+  AQ_HIP(hipEventRecord(e0, 0));
+#define AQ_CASE(NT_, NW_, TT_)                                                             \
+  if (s->NT == NT_ && s->NW == NW_ && s->TT == TT_) {                                      \
+    hipLaunchKernelGGL((aq_core_sweep_kernel<NT_, NW_, TT_>), grid, block, 0, 0, a);       \
+  } else
+  AQ_CASE(2, 4, 1) AQ_CASE(4, 4, 1) AQ_CASE(8, 4, 1) AQ_CASE(16, 4, 1) AQ_CASE(16, 8, 1)
+  AQ_CASE(2, 4, 3) AQ_CASE(4, 4, 3) AQ_CASE(8, 4, 3) AQ_CASE(16, 4, 3) {
+    return aq_fail(AQ_ERR_UNSUPPORTED, "no core kernel instantiation for this n");
+  }
+#undef AQ_CASE
+  AQ_HIP(hipEventRecord(e1, 0));
+  AQ_HIP(hipGetLastError());
+  if (mode == 0) {
+    s->ev.push_back({e0, e1});
+  } else {
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+  }
+  return AQ_OK;
+}
+
+static AqQvec aq_qvec(aq_vb *s) {
+  AqQvec v;
+  v.eta_h = s->eta_h; v.kappa_h = s->kappa_h; v.n0 = s->n0; v.nobs = s->nobs;
+  v.zeta = s->zeta; v.tau = s->tau; v.sig2b = s->sig2b; v.log_tau = s->log_tau; v.eta_vb = s->eta_vb;
+  v.kappa_vb = s->kappa_vb; v.coef = s->coef; v.inv2s = s->inv2s; v.cst = s->cst; v.sums = s->sums;
+  v.colApart = s->colApart; v.nchunk = s->nHchunk;
+  v.q = s->q; v.q_pad = s->q_pad; v.n = s->n; v.nu_h = s->nu; v.rho_h = s->rho;
+  return v;
+}
+static AqPvec aq_pvec(aq_vb *s) {
+  AqPvec v;
+  v.theta = s->theta; v.sig2_theta = s->sig2_theta; v.L = s->L; v.lam2_inv = s->lam2_inv; v.Q = s->Q;
+  v.rsZ = s->red; v.part = s->ppart; v.p = s->p; v.p_pad = s->p_pad; v.shr = s->shr; v.m0 = s->m0;
+  v.A2_inv = s->A2_inv; v.df = 1.0;
+  return v;
+}
+
+extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
+  if (!pr || !out) return aq_fail(AQ_ERR_ARG, "aq_vb_create: NULL argument");
+  *out = nullptr;
+  if (pr->n < 2 || pr->p < 1 || pr->q < 1) return aq_fail(AQ_ERR_ARG, "aq_vb_create: n >= 2, p >= 1, q >= 1 required");
+  if (pr->q_total < pr->q) return aq_fail(AQ_ERR_ARG, "aq_vb_create: q_total < q");
+  if (!pr->X || !pr->Y || !pr->eta || !pr->kappa || !pr->n0 || !pr->gam_vb || !pr->mu_beta_vb || !pr->sig2_beta_vb ||
+      !pr->sig2_theta_vb || !pr->tau_vb || !pr->theta_vb || !pr->zeta_vb)
+    return aq_fail(AQ_ERR_ARG, "aq_vb_create: NULL data pointer");
+  if (!(pr->tol > 0)) return aq_fail(AQ_ERR_ARG, "tol must be positive");
+  if (pr->maxit < 1) return aq_fail(AQ_ERR_ARG, "maxit must be natural.");
+  if (pr->has_anneal) {   // check_annealing_, R/prepare_atlasqtl.R:100-124
+    int type = (int)std::llround(pr->anneal[0]);
+    if (type < 1 || type > 3)
+      return aq_fail(AQ_ERR_ARG, "The annealing spacing scheme must be set to 1 for geometric 2 for harmonic or 3 for linear spacing.");
+    if (pr->anneal[1] < 1.5) return aq_fail(AQ_ERR_ARG, "Initial annealing temperature very small.");
+    if (pr->anneal[2] > 1000 || pr->anneal[2] < 2) return aq_fail(AQ_ERR_ARG, "Temperature grid size out of range.");
+  }
+  if (pr->world_size < 1) return aq_fail(AQ_ERR_ARG, "world_size must be >= 1");
+  AQ_TRY(aq_need_device(pr->device));
+
+  // X must be complete; Y may hold NaN
+  size_t np = (size_t)pr->n * pr->p, nq = (size_t)pr->n * pr->q;
+  for (size_t i = 0; i < np; i++)
+    if (!(pr->X[i] == pr->X[i])) return aq_fail(AQ_ERR_ARG, "X must be a non-empty a numeric matrix, finite without missing value.");
+  bool has_missing = false;
+  for (size_t i = 0; i < nq && !has_missing; i++) has_missing = !(pr->Y[i] == pr->Y[i]);
+  if (has_missing)
+    return aq_fail(AQ_ERR_UNSUPPORTED,
+                   "missing values in Y are not handled by the n-space device path yet (use aq_core_dual_mis_loop at operator level)");
+
+  aq_vb *s = new aq_vb();
+  s->device = pr->device;
+  s->n = pr->n; s->p = pr->p; s->q = pr->q; s->q_total = pr->q_total; s->world = pr->world_size;
+  s->p_pad = (pr->p + 15) / 16 * 16;
+  s->q_pad = (pr->q + 15) / 16 * 16;
+  s->nb = s->p_pad / 16;
+  s->ntile = s->q_pad / 16;
+  // residual tile geometry: n_pad = 16 * NT * NW samples
+  if (pr->n <= 128) { s->NT = 2; s->NW = 4; }
+  else if (pr->n <= 256) { s->NT = 4; s->NW = 4; }
+  else if (pr->n <= 512) { s->NT = 8; s->NW = 4; }
+  else if (pr->n <= 1024) { s->NT = 16; s->NW = 4; }
+  else if (pr->n <= 2048) { s->NT = 16; s->NW = 8; }
+  else {
+    delete s;
+    return aq_fail(AQ_ERR_UNSUPPORTED, "n > 2048: the register-resident residual tile does not fit (not implemented yet)");
+  }
+  s->n_pad = 16 * s->NT * s->NW;
+  // trait tiles per workgroup: 1 (two workgroups per CU) unless that would need a second round of workgroups
+  s->TT = 1;
+  if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 3 ? 3 : 1;
+  else if (s->NW == 4 && s->ntile > 512) s->TT = 3;
+  if (s->NW != 4) s->TT = 1;
+  int rc = aq_probe_dmode(&s->dmode);
+  if (rc != AQ_OK) { delete s; return rc; }
+
+  s->A2_inv = pr->A2_inv; s->m0 = pr->m0; s->nu = pr->nu; s->rho = pr->rho; s->t02 = pr->t02;
+  s->t02_inv = 1.0 / pr->t02;
+  s->shr = (double)pr->q_total;   // shr_fac_inv <- q, R/atlasqtl.R:218
+  s->has_anneal = pr->has_anneal != 0;
+  std::memcpy(s->anneal, pr->anneal, sizeof(s->anneal));
+  s->tol = pr->tol; s->maxit = pr->maxit; s->thinned = pr->thinned_elbo_eval != 0; s->debug = pr->debug != 0;
+  s->has_missing = has_missing;
+
+  auto fail = [&](int code) { aq_free_all(s); return code; };
+#define AQ_TRYF(x) do { int rc2_ = (x); if (rc2_ != AQ_OK) return fail(rc2_); } while (0)
+#define AQ_HIPF(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { aq_fail(AQ_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(AQ_ERR_DEVICE); } } while (0)
+
+  const int NTT = s->NT * s->NW;
+  size_t xelems = (size_t)s->nb * NTT * 128;
+  AQ_TRYF(aq_dalloc(&s->XA, xelems));
+  AQ_TRYF(aq_dalloc(&s->XU, xelems));
+  AQ_TRYF(aq_dalloc(&s->G, (size_t)s->nb * 256));
+  AQ_TRYF(aq_dalloc(&s->R, (size_t)s->ntile * s->n_pad * 16));
+  AQ_TRYF(aq_dalloc(&s->gam, (size_t)s->ntile * s->p_pad * 16));
+  AQ_TRYF(aq_dalloc(&s->mu, (size_t)s->ntile * s->p_pad * 16));
+  AQ_TRYF(aq_dalloc(&s->theta, (size_t)s->p_pad));
+  AQ_TRYF(aq_dalloc(&s->sig2_theta, (size_t)s->p_pad));
+  AQ_TRYF(aq_dalloc(&s->L, (size_t)s->p_pad));
+  AQ_TRYF(aq_dalloc(&s->lam2_inv, (size_t)s->p_pad));
+  AQ_TRYF(aq_dalloc(&s->Q, (size_t)s->p_pad));
+  s->pblk = (s->p + 255) / 256;
+  AQ_TRYF(aq_dalloc(&s->ppart, (size_t)3 * s->pblk));
+  double **qv[] = {&s->eta_h, &s->kappa_h, &s->n0, &s->nobs, &s->zeta, &s->tau, &s->sig2b, &s->log_tau, &s->eta_vb,
+                   &s->kappa_vb, &s->coef, &s->inv2s, &s->cst};
+  for (double **qp : qv) AQ_TRYF(aq_dalloc(qp, (size_t)s->q_pad));
+  AQ_TRYF(aq_dalloc(&s->sums, (size_t)5 * s->q_pad));
+  AQ_TRYF(aq_dalloc(&s->rowA, (size_t)s->ntile * s->p_pad));
+  AQ_TRYF(aq_dalloc(&s->rowGB, (size_t)s->ntile * s->p_pad));
+  AQ_TRYF(aq_dalloc(&s->Aarr, (size_t)s->ntile * s->p_pad * 16));
+  AQ_TRYF(aq_dalloc(&s->Barr, (size_t)s->ntile * s->p_pad * 16));
+  if (pr->ext_reduce_main) { s->red = pr->ext_reduce_main; s->own_red = false; }
+  else { AQ_TRYF(aq_dalloc(&s->red, (size_t)aq_vb_reduce_len(s->p))); s->own_red = true; }
+  if (pr->ext_reduce_elbo) { s->ered = pr->ext_reduce_elbo; s->own_ered = false; }
+  else { AQ_TRYF(aq_dalloc(&s->ered, (size_t)8)); s->own_ered = true; }
+  s->rows_per_chunk = 2048;
+  s->nHchunk = (s->p_pad + s->rows_per_chunk - 1) / s->rows_per_chunk;
+  AQ_TRYF(aq_dalloc(&s->Hpart, (size_t)s->ntile * s->nHchunk));
+  AQ_TRYF(aq_dalloc(&s->colApart, (size_t)s->nHchunk * s->q_pad));
+  AQ_TRYF(aq_dalloc(&s->sc, (size_t)1));
+
+  // ---- uploads + layout conversion (staging buffers freed afterwards) ----
+  {
+    double *Xd = nullptr;
+    AQ_HIPF(hipMalloc((void **)&Xd, np * sizeof(double)));
+    AQ_HIPF(hipMemcpy(Xd, pr->X, np * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(aq_k_build_x_layouts, dim3((unsigned)((xelems + 255) / 256)), dim3(256), 0, 0, Xd, s->XA, s->XU,
+                       s->n, s->p, s->nb, NTT, s->dmode);
+    hipLaunchKernelGGL(aq_k_gram_blocks, dim3(s->nb), dim3(256), 0, 0, Xd, s->G, s->n, s->p);
+    AQ_HIPF(hipDeviceSynchronize());
+    AQ_HIPF(hipFree(Xd));
+  }
+  {
+    size_t big = std::max((size_t)pr->p * pr->q, nq);
+    double *stage = nullptr;
+    AQ_HIPF(hipMalloc((void **)&stage, big * sizeof(double)));
+    AQ_HIPF(hipMemcpy(stage, pr->Y, nq * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->n_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->R,
+                       s->n, s->q, s->n_pad, 1);
+    AQ_HIPF(hipDeviceSynchronize());
+    size_t pq = (size_t)pr->p * pr->q;
+    AQ_HIPF(hipMemcpy(stage, pr->gam_vb, pq * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->p_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->gam,
+                       s->p, s->q, s->p_pad, 0);
+    AQ_HIPF(hipDeviceSynchronize());
+    AQ_HIPF(hipMemcpy(stage, pr->mu_beta_vb, pq * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->p_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->mu,
+                       s->p, s->q, s->p_pad, 0);
+    AQ_HIPF(hipDeviceSynchronize());
+    AQ_HIPF(hipFree(stage));
+  }
+  AQ_TRYF(aq_upload_padded(s->theta, pr->theta_vb, s->p, s->p_pad));
+  AQ_TRYF(aq_upload_padded(s->sig2_theta, pr->sig2_theta_vb, s->p, s->p_pad));
+  AQ_TRYF(aq_upload_padded(s->eta_h, pr->eta, s->q, s->q_pad));
+  AQ_TRYF(aq_upload_padded(s->kappa_h, pr->kappa, s->q, s->q_pad));
+  AQ_TRYF(aq_upload_padded(s->n0, pr->n0, s->q, s->q_pad));
+  AQ_TRYF(aq_upload_padded(s->zeta, pr->zeta_vb, s->q, s->q_pad));
+  AQ_TRYF(aq_upload_padded(s->tau, pr->tau_vb, s->q, s->q_pad));
+  AQ_TRYF(aq_upload_padded(s->sig2b, pr->sig2_beta_vb, s->q, s->q_pad));
+  {
+    std::vector<double> nobs(s->q_pad, 0.0);
+    for (int k = 0; k < s->q; k++) nobs[k] = (double)s->n;   // colSums(mis_pat); complete Y here
+    AQ_HIPF(hipMemcpy(s->nobs, nobs.data(), nobs.size() * sizeof(double), hipMemcpyHostToDevice));
+    // padded traits need valid constants for the init-mode core kernel (coef/inv2s/cst unused there)
+    std::vector<double> ones(s->q_pad, 1.0);
+    AQ_HIPF(hipMemcpy(s->inv2s, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (s->q_pad > s->q) {
+      AQ_HIPF(hipMemcpy(s->sig2b + s->q, ones.data(), (size_t)(s->q_pad - s->q) * sizeof(double), hipMemcpyHostToDevice));
+      AQ_HIPF(hipMemcpy(s->tau + s->q, ones.data(), (size_t)(s->q_pad - s->q) * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  {
+    AqScalars h;
+    std::memset(&h, 0, sizeof(h));
+    h.sig02_inv = pr->sig02_inv_vb;
+    h.lentz_mask[0] = h.lentz_mask[1] = ~0ull;
+    AQ_HIPF(hipMemcpy(s->sc, &h, sizeof(h), hipMemcpyHostToDevice));
+  }
+
+  // ---- host loop state, R/atlasqtl_global_local_core.R:71-123 ----
+  if (!s->has_anneal) {
+    s->annealing = false; s->c = s->c_s = 1.0; s->it_init = 1;
+  } else {
+    s->annealing = true;
+    s->ladder = aq_ladder(s->anneal);
+    s->c = s->ladder[0]; s->c_s = s->c;            // anneal_scale <- TRUE
+    s->it_init = (int)std::llround(s->anneal[2]);
+  }
+  if (s->thinned) { s->times_conv_sched = {1, 5, 10, 50}; s->batch_conv_sched = {1, 10, 25, 50}; }
+  else { s->times_conv_sched = {1}; s->batch_conv_sched = {1}; }
+  s->ind_batch_conv = (int)s->batch_conv_sched.size() + 1;
+  s->batch_conv = 1;
+  s->sig2_zeta = 1.0 / (s->c * ((double)s->p + s->t02_inv));                       // update_sig2_c0_vb_(p, t02, c), :105
+  s->vec_sum_log_det_zeta = -(double)s->q_total * (std::log(s->t02) + std::log((double)s->p + s->t02_inv));   // :107
+  s->phase = 0;
+  *out = s;
+  return AQ_OK;
+}
+
+extern "C" void aq_vb_destroy(aq_vb_handle h) { aq_free_all(h); }
+
+extern "C" double *aq_vb_reduce_ptr(aq_vb_handle h, int32_t which) {
+  if (!h) return nullptr;
+  return which == 0 ? h->red : h->ered;
+}
+
+// part A of a sweep: S1-S11 + local reductions into the all-reduce payload
+static int aq_launch_prepass(aq_vb *s, double c, int do_H) {
+  AqPrepass v;
+  v.theta = s->theta; v.zeta = s->zeta; v.gam = s->gam; v.Aarr = s->Aarr; v.Barr = s->Barr; v.rowA = s->rowA;
+  v.colApart = s->colApart; v.Hpart = s->Hpart; v.p = s->p; v.q = s->q; v.p_pad = s->p_pad; v.q_pad = s->q_pad;
+  v.rows_per_chunk = s->rows_per_chunk; v.sqrt_c = std::sqrt(c);
+  v.c_is_one = std::fabs(c - 1.0) < 1.5e-8 ? 1 : 0;   // isTRUE(all.equal(c, 1)), R/update_vb.R:219
+  v.do_H = do_H;
+  hipLaunchKernelGGL(aq_k_prepass, dim3(s->nHchunk, s->ntile), dim3(256), 0, 0, v);
+  AQ_HIP(hipGetLastError());
+  return AQ_OK;
+}
+
+static int aq_sweep_part_a(aq_vb *s) {
+  AqQvec qv = aq_qvec(s);
+  if (!s->pre_done) AQ_TRY(aq_launch_prepass(s, s->c, 0));
+  s->pre_done = false;
+  hipLaunchKernelGGL(aq_k_qpre, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, qv, s->sc, s->c);
+  AQ_TRY(aq_launch_core(s, 0, s->c));
+  hipLaunchKernelGGL(aq_k_reduce_rows, dim3((s->p_pad + 255) / 256), dim3(256), 0, 0, s->rowA, s->rowGB, s->red, s->ntile, s->p_pad);
+  hipLaunchKernelGGL(aq_k_reduce_q_scalars, dim3(1), dim3(1024), 0, 0, qv, s->red + s->p_pad);
+  AQ_HIP(hipGetLastError());
+  return AQ_OK;
+}
+
+// part B: S12-S20 on the all-reduced sums, then the ladder step (host scalars)
+static int aq_sweep_part_b(aq_vb *s) {
+  AqQvec qv = aq_qvec(s);
+  AqPvec pv = aq_pvec(s);
+  int ann = (s->annealing) ? 1 : 0;   // annealing & anneal_scale, :244
+  hipLaunchKernelGGL(aq_k_take_reduced_scalars, dim3(1), dim3(1), 0, 0, s->sc, s->red + s->p_pad);
+  hipLaunchKernelGGL(aq_k_reset_lentz, dim3(1), dim3(1), 0, 0, s->sc);
+  hipLaunchKernelGGL(aq_k_pvec_L, dim3(s->pblk), dim3(256), 0, 0, pv, s->sc, s->c_s, ann);
+  hipLaunchKernelGGL(aq_k_pvec_finish, dim3(s->pblk), dim3(256), 0, 0, pv, s->sc, s->c, s->c_s, ann, s->q_total);
+  hipLaunchKernelGGL(aq_k_scalars_post, dim3(1), dim3(1024), 0, 0, pv, s->sc, s->c_s, s->pblk);
+  hipLaunchKernelGGL(aq_k_qpost, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, qv, s->sc, s->c, s->sig2_zeta, s->t02_inv);
+  AQ_HIP(hipGetLastError());
+  return AQ_OK;
+}
+
+static int aq_elbo_local(aq_vb *s) {
+  AqQvec qv = aq_qvec(s);
+  AqPvec pv = aq_pvec(s);
+  // the pre-pass of the NEXT sweep (same refreshed theta + zeta, c = 1 here) also yields the p x q ELBO part
+  AQ_TRY(aq_launch_prepass(s, s->c, 1));
+  s->pre_done = true;
+  hipLaunchKernelGGL(aq_k_elbo_C, dim3(1), dim3(1024), 0, 0, pv, s->sc);
+  hipLaunchKernelGGL(aq_k_elbo_q, dim3(1), dim3(1024), 0, 0, qv, s->sc, s->Hpart, s->ntile * s->nHchunk, s->ered);
+  AQ_HIP(hipGetLastError());
+  return AQ_OK;
+}
+
+static int aq_elbo_finish(aq_vb *s, double *lb) {
+  AqElboConst k;
+  k.nu_h = s->nu; k.rho_h = s->rho; k.A2_inv = s->A2_inv; k.t02_inv = s->t02_inv;
+  k.vec_sum_log_det_zeta = s->vec_sum_log_det_zeta; k.sig2_zeta = s->sig2_zeta;
+  k.p = (double)s->p; k.q_total = (double)s->q_total;
+  hipLaunchKernelGGL(aq_k_elbo_final, dim3(1), dim3(1), 0, 0, s->sc, s->ered, k);
+  AQ_HIP(hipGetLastError());
+  AqScalars h;
+  AQ_HIP(hipMemcpy(&h, s->sc, sizeof(h), hipMemcpyDeviceToHost));
+  *lb = h.elbo;
+  return AQ_OK;
+}
+
+static bool aq_all_equal_1(double c) { return std::fabs(c - 1.0) < 1.5e-8; }
+
+// One step of the state machine.  stop_after_sweeps < 0: unlimited.
+static int aq_advance_impl(aq_vb *s, int *sweeps_budget) {
+  if (s->failed) return -aq_fail(AQ_ERR_NUMERIC, "handle is in a failed state");
+  AQ_HIP(hipSetDevice(s->device));
+  for (;;) {
+    switch (s->phase) {
+      case 0: {   // initial residual R = Y - X beta_vb (:112-115 in n-space) and the initial column sums
+        AQ_TRY(aq_launch_core(s, 1, 1.0));
+        AQ_HIP(hipMemsetAsync(s->red, 0, (size_t)aq_vb_reduce_len(s->p) * sizeof(double), 0));
+        AqQvec qv = aq_qvec(s);
+        hipLaunchKernelGGL(aq_k_reduce_q_scalars, dim3(1), dim3(1024), 0, 0, qv, s->red + s->p_pad);
+        AQ_HIP(hipGetLastError());
+        s->phase = 1;
+        return AQ_VB_NEED_ALLREDUCE_MAIN;
+      }
+      case 1:
+        hipLaunchKernelGGL(aq_k_take_reduced_scalars, dim3(1), dim3(1), 0, 0, s->sc, s->red + s->p_pad);
+        s->phase = 2;
+        break;
+      case 2:
+        if (s->converged || s->it >= s->maxit) return AQ_VB_DONE;                  // :125
+        if (sweeps_budget) {
+          if (*sweeps_budget == 0) return AQ_VB_DONE;
+          (*sweeps_budget)--;
+        }
+        s->lb_old = s->lb_new;                                                     // :127
+        s->it += 1;
+        AQ_TRY(aq_sweep_part_a(s));
+        s->phase = 3;
+        return AQ_VB_NEED_ALLREDUCE_MAIN;
+      case 3: {
+        AQ_TRY(aq_sweep_part_b(s));
+        if (s->annealing) {                                                        // :318-337
+          s->sig2_zeta = s->c * s->sig2_zeta;
+          s->c = (s->it < (int)s->ladder.size()) ? s->ladder[s->it] : 1.0;         // ladder[it + 1], 1-based
+          s->c_s = s->c;
+          s->sig2_zeta = s->sig2_zeta / s->c;
+          if (aq_all_equal_1(s->c)) s->annealing = false;
+          s->phase = 2;
+          break;
+        }
+        bool eval = (s->it <= s->it_init + 1) || (s->it % s->batch_conv == 0) || (s->it % s->batch_conv == 1);   // :342
+        if (!eval) {
+          s->phase = 2;
+          break;
+        }
+        AQ_TRY(aq_elbo_local(s));
+        s->phase = 4;
+        return AQ_VB_NEED_ALLREDUCE_ELBO;
+      }
+      case 4: {
+        double lb;
+        AQ_TRY(aq_elbo_finish(s, &lb));
+        s->lb_new = lb;
+        s->trace_it.push_back(s->it);
+        s->trace_lb.push_back(lb);
+        const double eps = std::sqrt(std::numeric_limits<double>::epsilon());      // :85
+        if (s->debug && lb + eps < s->lb_old) {                                    // :359-360
+          s->failed = true;
+          char buf[256];
+          std::snprintf(buf, sizeof(buf), "ELBO not increasing monotonically. Exit. (it=%d, lb_old=%.17g, lb_new=%.17g)", s->it,
+                        s->lb_old, lb);
+          return -aq_fail(AQ_ERR_NUMERIC, buf);
+        }
+        double diff = std::fabs(lb - s->lb_old);                                   // :362
+        int sum_exceed = 0;
+        for (double t : s->times_conv_sched) sum_exceed += (diff > t * s->tol) ? 1 : 0;   // :364
+        if (sum_exceed == 0) {
+          s->converged = true;
+        } else if (s->ind_batch_conv > sum_exceed) {
+          s->ind_batch_conv = sum_exceed;
+          s->batch_conv = s->batch_conv_sched[sum_exceed - 1];
+        }
+        s->phase = 2;
+        break;
+      }
+      default:
+        return -aq_fail(AQ_ERR_ARG, "corrupt state");
+    }
+  }
+}
+
+extern "C" int aq_vb_advance(aq_vb_handle h) {
+  if (!h) return -aq_fail(AQ_ERR_ARG, "NULL handle");
+  int rc = aq_advance_impl(h, nullptr);
+  return rc;
+}
+
+static int aq_run_impl(aq_vb *s, int *budget) {
+  if (s->world != 1) return aq_fail(AQ_ERR_ARG, "aq_vb_run: world_size != 1 needs the aq_vb_advance protocol");
+  for (;;) {
+    int rc = aq_advance_impl(s, budget);
+    if (rc < 0) return -rc;
+    if (rc == AQ_VB_DONE) break;
+  }
+  AQ_HIP(hipDeviceSynchronize());
+  return AQ_OK;
+}
+extern "C" int aq_vb_run(aq_vb_handle h) {
+  if (!h) return aq_fail(AQ_ERR_ARG, "NULL handle");
+  return aq_run_impl(h, nullptr);
+}
+extern "C" int aq_vb_run_sweeps(aq_vb_handle h, int32_t max_sweeps) {
+  if (!h) return aq_fail(AQ_ERR_ARG, "NULL handle");
+  int budget = max_sweeps;
+  return aq_run_impl(h, &budget);
+}
+
+static void aq_resolve_events(aq_vb *s) {
+  for (auto &e : s->ev) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+      s->core_ms_acc += ms;
+      s->core_launches++;
+    }
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  s->ev.clear();
+}
+
+extern "C" int aq_vb_get_status(aq_vb_handle s, aq_vb_status *st) {
+  if (!s || !st) return aq_fail(AQ_ERR_ARG, "NULL argument");
+  AQ_HIP(hipSetDevice(s->device));
+  aq_resolve_events(s);
+  AqScalars h;
+  AQ_HIP(hipMemcpy(&h, s->sc, sizeof(h), hipMemcpyDeviceToHost));
+  st->it = s->it;
+  st->converged = s->converged ? 1 : 0;
+  st->lb_opt = s->lb_new;
+  st->diff_lb = std::fabs(s->lb_new - s->lb_old);
+  st->c = s->c;
+  st->annealing = s->annealing ? 1 : 0;
+  st->n_elbo = (int)s->trace_it.size();
+  st->core_ms = s->core_ms_acc;
+  st->core_launches = s->core_launches;
+  st->sig02_inv_vb = h.sig02_inv;
+  st->sig2_inv_vb = h.sig2_inv;
+  st->lentz_iters = h.lentz_iters;
+  return AQ_OK;
+}
+
+extern "C" int32_t aq_vb_get_elbo_trace(aq_vb_handle s, int32_t *it_out, double *lb_out, int32_t cap) {
+  if (!s) return 0;
+  int n = (int)s->trace_it.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    if (it_out) it_out[i] = s->trace_it[i];
+    if (lb_out) lb_out[i] = s->trace_lb[i];
+  }
+  return n;
+}
+
+extern "C" int aq_vb_get_result(aq_vb_handle s, double *beta_vb, double *gam_vb, double *mu_beta_vb, double *theta_vb,
+                                double *zeta_vb, double *lam2_inv_vb, double *sig2_theta_vb, double *tau_vb,
+                                double *sig2_beta_vb) {
+  if (!s) return aq_fail(AQ_ERR_ARG, "NULL handle");
+  AQ_HIP(hipSetDevice(s->device));
+  AQ_HIP(hipDeviceSynchronize());
+  size_t pq = (size_t)s->p * s->q;
+  if (beta_vb || gam_vb || mu_beta_vb) {
+    double *stage;
+    AQ_HIP(hipMalloc((void **)&stage, pq * sizeof(double)));
+    dim3 grid((s->p_pad + 63) / 64, s->ntile);
+    struct { double *dst; const double *src; const double *mul; } jobs[3] = {
+        {beta_vb, s->gam, s->mu}, {gam_vb, s->gam, nullptr}, {mu_beta_vb, s->mu, nullptr}};
+    for (auto &j : jobs) {
+      if (!j.dst) continue;
+      hipLaunchKernelGGL(aq_k_colmajor_from_tile, grid, dim3(256), 0, 0, j.src, j.mul, stage, s->p, s->q, s->p_pad);
+      hipError_t e = hipMemcpy(j.dst, stage, pq * sizeof(double), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { hipFree(stage); return aq_fail(AQ_ERR_DEVICE, hipGetErrorString(e)); }
+    }
+    AQ_HIP(hipFree(stage));
+  }
+  if (theta_vb) AQ_HIP(hipMemcpy(theta_vb, s->theta, (size_t)s->p * sizeof(double), hipMemcpyDeviceToHost));
+  if (zeta_vb) AQ_HIP(hipMemcpy(zeta_vb, s->zeta, (size_t)s->q * sizeof(double), hipMemcpyDeviceToHost));
+  if (lam2_inv_vb) AQ_HIP(hipMemcpy(lam2_inv_vb, s->lam2_inv, (size_t)s->p * sizeof(double), hipMemcpyDeviceToHost));
+  if (sig2_theta_vb) AQ_HIP(hipMemcpy(sig2_theta_vb, s->sig2_theta, (size_t)s->p * sizeof(double), hipMemcpyDeviceToHost));
+  if (tau_vb) AQ_HIP(hipMemcpy(tau_vb, s->tau, (size_t)s->q * sizeof(double), hipMemcpyDeviceToHost));
+  if (sig2_beta_vb) AQ_HIP(hipMemcpy(sig2_beta_vb, s->sig2b, (size_t)s->q * sizeof(double), hipMemcpyDeviceToHost));
+  return AQ_OK;
+}
+
+// ------------------------------------------------- operator-level entries ----
+static int aq_gram_common(bool mis, const double *cp_X, const double *const *cp_X_rm, const double *cp_Y_X, double *gam_vb,
+                          const double *lP, const double *l1, double log_sig2_inv_vb, const double *log_tau_vb,
+                          double *m1_beta, double *cp_betaX_X, double *mu_beta_vb, const double *sig2_beta_vb,
+                          const double *tau_vb, const int32_t *shuffled_ind, int32_t n_ind, const int32_t *sample_q,
+                          int32_t n_q, double c, int32_t p, int32_t q) {
+  if (!cp_X || !cp_Y_X || !gam_vb || !lP || !l1 || !log_tau_vb || !m1_beta || !cp_betaX_X || !mu_beta_vb || !sig2_beta_vb ||
+      !tau_vb || (mis && !cp_X_rm))
+    return aq_fail(AQ_ERR_ARG, "aq_core_dual_loop: NULL argument");
+  if (p < 1 || q < 1 || n_ind < 0 || n_q < 0) return aq_fail(AQ_ERR_ARG, "aq_core_dual_loop: bad sizes");
+  if ((n_ind > 0 && !shuffled_ind) || (n_q > 0 && !sample_q)) return aq_fail(AQ_ERR_ARG, "aq_core_dual_loop: NULL index vector");
+  for (int i = 0; i < n_ind; i++)
+    if (shuffled_ind[i] < 0 || shuffled_ind[i] >= p) return aq_fail(AQ_ERR_ARG, "shuffled_ind out of range [0, p)");
+  {
+    std::vector<char> seen((size_t)q, 0);
+    for (int i = 0; i < n_q; i++) {
+      if (sample_q[i] < 0 || sample_q[i] >= q) return aq_fail(AQ_ERR_ARG, "sample_q out of range [0, q)");
+      if (seen[sample_q[i]]) return aq_fail(AQ_ERR_ARG, "sample_q holds a repeated trait index");
+      seen[sample_q[i]] = 1;
+    }
+  }
+  AQ_TRY(aq_need_device(0));
+  if (n_ind == 0 || n_q == 0) return AQ_OK;   // empty index vectors: nothing to do (the reference's loops do not execute)
+
+  size_t pp = (size_t)p * p, pq = (size_t)p * q;
+  std::vector<void *> to_free;
+  auto cleanup = [&]() { for (void *x : to_free) hipFree(x); };
+  auto up = [&](const void *src, size_t bytes, void **dst) -> int {
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return aq_fail(AQ_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    to_free.push_back(*dst);
+    e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return aq_fail(AQ_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    return AQ_OK;
+  };
+#define AQ_UP(src, count, dst)                                            \
+  do {                                                                    \
+    int rcu_ = up((src), (count) * sizeof(*(src)), (void **)&(dst));      \
+    if (rcu_ != AQ_OK) { cleanup(); return rcu_; }                        \
+  } while (0)
+  AqGramArgs a;
+  std::memset(&a, 0, sizeof(a));
+  double *d_cpX, *d_cpYX, *d_gam, *d_lP, *d_l1, *d_lt, *d_m1, *d_bx, *d_mu, *d_s2, *d_tau;
+  int32_t *d_si, *d_sq;
+  AQ_UP(cp_X, pp, d_cpX);
+  AQ_UP(cp_Y_X, pq, d_cpYX);
+  AQ_UP(gam_vb, pq, d_gam);
+  AQ_UP(lP, pq, d_lP);
+  AQ_UP(l1, pq, d_l1);
+  AQ_UP(log_tau_vb, (size_t)q, d_lt);
+  AQ_UP(m1_beta, pq, d_m1);
+  AQ_UP(cp_betaX_X, pq, d_bx);
+  AQ_UP(mu_beta_vb, pq, d_mu);
+  AQ_UP(sig2_beta_vb, mis ? pq : (size_t)q, d_s2);
+  AQ_UP(tau_vb, (size_t)q, d_tau);
+  AQ_UP(shuffled_ind, (size_t)n_ind, d_si);
+  AQ_UP(sample_q, (size_t)n_q, d_sq);
+  const double **d_rm_arr = nullptr;
+  if (mis) {
+    std::vector<const double *> hp((size_t)q, nullptr);
+    for (int k = 0; k < q; k++) {
+      if (!cp_X_rm[k]) { cleanup(); return aq_fail(AQ_ERR_ARG, "cp_X_rm holds a NULL matrix"); }
+      double *dk;
+      AQ_UP(cp_X_rm[k], pp, dk);
+      hp[k] = dk;
+    }
+    const double **tmp;
+    int rcu = up(hp.data(), (size_t)q * sizeof(const double *), (void **)&tmp);
+    if (rcu != AQ_OK) { cleanup(); return rcu; }
+    d_rm_arr = tmp;
+  }
+  a.cp_X = d_cpX; a.cp_X_rm = d_rm_arr; a.cp_Y_X = d_cpYX; a.gam_vb = d_gam; a.log_Phi = d_lP; a.log_1mPhi = d_l1;
+  a.log_sig2_inv_vb = log_sig2_inv_vb; a.log_tau_vb = d_lt; a.m1_beta = d_m1; a.cp_betaX_X = d_bx; a.mu_beta_vb = d_mu;
+  a.sig2_beta_vb = d_s2; a.tau_vb = d_tau; a.shuffled_ind = d_si; a.n_ind = n_ind; a.sample_q = d_sq; a.n_q = n_q;
+  a.c = c; a.p = p; a.q = q;
+  int grid = n_q < 2048 ? n_q : 2048;
+  if (mis) hipLaunchKernelGGL((aq_gram_loop_kernel<true>), dim3(grid), dim3(256), 0, 0, a);
+  else hipLaunchKernelGGL((aq_gram_loop_kernel<false>), dim3(grid), dim3(256), 0, 0, a);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(gam_vb, d_gam, pq * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(m1_beta, d_m1, pq * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(cp_betaX_X, d_bx, pq * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(mu_beta_vb, d_mu, pq * sizeof(double), hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return aq_fail(AQ_ERR_DEVICE, std::string("aq_core_dual_loop: ") + hipGetErrorString(e));
+  return AQ_OK;
+#undef AQ_UP
+}
+
+extern "C" int aq_core_dual_loop(const double *cp_X, const double *cp_Y_X, double *gam_vb, const double *lP, const double *l1,
+                                 double log_sig2_inv_vb, const double *log_tau_vb, double *m1_beta, double *cp_betaX_X,
+                                 double *mu_beta_vb, const double *sig2_beta_vb, const double *tau_vb,
+                                 const int32_t *shuffled_ind, int32_t n_ind, const int32_t *sample_q, int32_t n_q, double c,
+                                 int32_t p, int32_t q) {
+  return aq_gram_common(false, cp_X, nullptr, cp_Y_X, gam_vb, lP, l1, log_sig2_inv_vb, log_tau_vb, m1_beta, cp_betaX_X,
+                        mu_beta_vb, sig2_beta_vb, tau_vb, shuffled_ind, n_ind, sample_q, n_q, c, p, q);
+}
+extern "C" int aq_core_dual_mis_loop(const double *cp_X, const double *const *cp_X_rm, const double *cp_Y_X, double *gam_vb,
+                                     const double *lP, const double *l1, double log_sig2_inv_vb, const double *log_tau_vb,
+                                     double *m1_beta, double *cp_betaX_X, double *mu_beta_vb, const double *sig2_beta_vb,
+                                     const double *tau_vb, const int32_t *shuffled_ind, int32_t n_ind,
+                                     const int32_t *sample_q, int32_t n_q, double c, int32_t p, int32_t q) {
+  return aq_gram_common(true, cp_X, cp_X_rm, cp_Y_X, gam_vb, lP, l1, log_sig2_inv_vb, log_tau_vb, m1_beta, cp_betaX_X,
+                        mu_beta_vb, sig2_beta_vb, tau_vb, shuffled_ind, n_ind, sample_q, n_q, c, p, q);
+}
+
+// ------------------------------------------------------------- test hooks ----
+extern "C" int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len) {
+  if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval: bad argument");
+  for (int64_t i = 0; i < len; i++) {
+    switch (which) {
+      case 0: out[i] = aq_log_ndtr(x[i]); break;
+      case 1: out[i] = aq_digamma(x[i]); break;
+      case 2: out[i] = aq_expint_e1_small(x[i]); break;
+      case 3:
+        if (!x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
+        out[i] = aq_gamma_inc_upper(x2[i], x[i]);
+        break;
+      case 4: out[i] = aq_sigmoid_neg(x[i]); break;
+      default: return aq_fail(AQ_ERR_ARG, "aq_special_eval: unknown function id");
+    }
+  }
+  return AQ_OK;
+}
+
+extern "C" int aq_q_approx_vec(const double *x, double *out, int64_t len, int32_t *iters) {
+  if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_q_approx_vec: bad argument");
+  unsigned long long m0 = ~0ull, m1 = ~0ull;
+  bool any = false;
+  for (int64_t i = 0; i < len; i++) {
+    if (x[i] > 1.0) {
+      AqLentz s;
+      aq_lentz_init(&s);
+      unsigned long long a0 = 0, a1 = 0;
+      for (int it = 0; it < 128; it++) {
+        double d = aq_lentz_step(&s, x[i], it + 2);
+        if (d < 1e-7) { if (it < 64) a0 |= 1ull << it; else a1 |= 1ull << (it - 64); }
+      }
+      m0 &= a0; m1 &= a1;
+      any = true;
+    }
+  }
+  int nit = 0;
+  if (any) nit = m0 ? __builtin_ffsll((long long)m0) : (m1 ? 64 + __builtin_ffsll((long long)m1) : 129);
+  for (int64_t i = 0; i < len; i++) {
+    if (x[i] <= 1.0) {
+      out[i] = aq_expint_e1_small(x[i]) * exp(x[i]);
+    } else {
+      AqLentz s;
+      aq_lentz_init(&s);
+      for (int it = 0; it < nit; it++) aq_lentz_step(&s, x[i], it + 2);
+      out[i] = aq_lentz_finish(&s, x[i]);
+    }
+  }
+  if (iters) *iters = nit;
+  return AQ_OK;
+}

@@ -1,0 +1,173 @@
+/*
+ * atlasqtl_hip.h -- C ABI of libatlasqtl_hip.so, the MI355X (gfx950) implementation of
+ * atlasqtl's variational-inference hot path.  Plain C: pointers + sizes, int status
+ * returns (0 = ok), thread-local message via aq_last_error().  No torch / R types.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository hruffieux/atlasqtl @ v0.1.5).  INTEGRATION.md shows the R-side
+ * binding (a .Call shim) a maintainer would add.
+ *
+ * All matrices are R layout: column-major fp64; indices are 0-based int32.
+ */
+#ifndef ATLASQTL_HIP_H_
+#define ATLASQTL_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AQ_OK 0
+#define AQ_ERR_ARG 1        /* bad argument (NULL, size, range) -- where the reference would stop()        */
+#define AQ_ERR_DEVICE 2     /* no gfx950 device / HIP runtime error                                        */
+#define AQ_ERR_UNSUPPORTED 3
+#define AQ_ERR_NUMERIC 4    /* "ELBO not increasing monotonically" (R/atlasqtl_global_local_core.R:359-360) */
+
+/* Message of the last failing call on this thread ("" if none). */
+const char *aq_last_error(void);
+/* Library version string. */
+const char *aq_version(void);
+/* Number of visible HIP devices (0 on a CPU-only host; never fails). */
+int aq_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entries: drop-in for the two native functions of the reference.
+ *
+ * aq_core_dual_loop replaces
+ *     SEXP _atlasqtl_coreDualLoop(SEXP x 15)                    src/RcppExports.cpp:17-38
+ *     void coreDualLoop(...)                                    src/coreLoop.cpp:38-86
+ * Same positional arguments (plus explicit sizes); cp_Y_X is q x p.  gam_vb, m1_beta,
+ * cp_betaX_X and mu_beta_vb (each p x q) are updated IN PLACE in the caller's host buffers,
+ * exactly as the reference mutates the R objects it is handed (src/RcppExports.cpp:22,27-29).
+ * Host pointers in, host pointers out; the arithmetic runs on the GPU in the reference's
+ * own Gram-space form and visiting order.  Indices are range-checked (AQ_ERR_ARG) where the
+ * reference has undefined behaviour.
+ * ---------------------------------------------------------------------------------------- */
+int aq_core_dual_loop(const double *cp_X, const double *cp_Y_X, double *gam_vb,
+                      const double *log_Phi_theta_plus_zeta, const double *log_1_min_Phi_theta_plus_zeta,
+                      double log_sig2_inv_vb, const double *log_tau_vb, double *m1_beta, double *cp_betaX_X,
+                      double *mu_beta_vb, const double *sig2_beta_vb /* q */, const double *tau_vb,
+                      const int32_t *shuffled_ind, int32_t n_ind, const int32_t *sample_q, int32_t n_q, double c,
+                      int32_t p, int32_t q);
+
+/* aq_core_dual_mis_loop replaces
+ *     SEXP _atlasqtl_coreDualMisLoop(SEXP x 16)                 src/RcppExports.cpp:41-62
+ *     void coreDualMisLoop(...)                                 src/coreLoop.cpp:91-138
+ * cp_X_rm: array of q pointers to p x p matrices (the reference's R list); sig2_beta_vb is p x q. */
+int aq_core_dual_mis_loop(const double *cp_X, const double *const *cp_X_rm, const double *cp_Y_X, double *gam_vb,
+                          const double *log_Phi_theta_plus_zeta, const double *log_1_min_Phi_theta_plus_zeta,
+                          double log_sig2_inv_vb, const double *log_tau_vb, double *m1_beta, double *cp_betaX_X,
+                          double *mu_beta_vb, const double *sig2_beta_vb /* p x q */, const double *tau_vb,
+                          const int32_t *shuffled_ind, int32_t n_ind, const int32_t *sample_q, int32_t n_q,
+                          double c, int32_t p, int32_t q);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-run entries: the device-resident replacement of
+ *     atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbose,
+ *                                 list_hyper, list_init, ...)   R/atlasqtl_global_local_core.R:8-433
+ * (its `while` loop :125-386 incl. elbo_global_local_ :440-495).  X must be the standardised
+ * matrix and Y the centred matrix that prepare_data_ (R/prepare_atlasqtl.R:57-83) produces.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct aq_vb *aq_vb_handle;
+
+typedef struct aq_vb_problem {
+  int32_t n, p;
+  int32_t q;            /* traits held by THIS process (columns of Y given here)                     */
+  int32_t q_total;      /* traits of the whole problem (= q on one GPU); shr_fac_inv = q_total        */
+  const double *X;      /* n x p, standardised, no NaN                                                */
+  const double *Y;      /* n x q, centred; NaN = missing (R/atlasqtl_global_local_core.R:19-22)       */
+  /* list_hyper fields (R/set_hyper_init.R:133-134) */
+  double A2_inv, m0, nu, rho, t02;
+  const double *eta;    /* q */
+  const double *kappa;  /* q */
+  const double *n0;     /* q */
+  /* list_init fields (R/set_hyper_init.R:344-346) */
+  const double *gam_vb;        /* p x q */
+  const double *mu_beta_vb;    /* p x q */
+  double sig02_inv_vb;
+  const double *sig2_beta_vb;  /* q */
+  const double *sig2_theta_vb; /* p */
+  const double *tau_vb;        /* q */
+  const double *theta_vb;      /* p */
+  const double *zeta_vb;       /* q */
+  /* control (R/atlasqtl.R:179-184) */
+  int32_t has_anneal;          /* 0 = anneal NULL */
+  double anneal[3];            /* type (1 geometric, 2 harmonic, 3 linear), initial temperature, ladder size */
+  double tol;
+  int32_t maxit;
+  int32_t thinned_elbo_eval;
+  int32_t debug;               /* 1: non-monotone ELBO -> AQ_ERR_NUMERIC, as the reference's stop()  */
+  /* placement */
+  int32_t device;              /* HIP device ordinal */
+  int32_t world_size;          /* number of cooperating processes (q-sharding); 1 = single GPU       */
+  double *ext_reduce_main;     /* optional DEVICE buffer of aq_vb_reduce_len() doubles owned by the
+                                  caller (e.g. a torch tensor) used as the all-reduce payload; NULL =
+                                  the library allocates it                                            */
+  double *ext_reduce_elbo;     /* optional DEVICE buffer of 8 doubles, same purpose                   */
+} aq_vb_problem;
+
+/* Length (in doubles) of the main all-reduce payload for a problem with p predictors:
+ * [ rowSums(Z) (p padded to 16) , sum(gam) , sum_k tau_k colSums(m2)_k , sum(zeta) , 5 spare ]. */
+int64_t aq_vb_reduce_len(int32_t p);
+
+int aq_vb_create(const aq_vb_problem *prob, aq_vb_handle *out);
+void aq_vb_destroy(aq_vb_handle h);
+
+/* State machine for the q-sharded multi-process run.  aq_vb_advance runs device work until a
+ * collective is needed or the run is over and returns one of the codes below (<0: error, see
+ * aq_last_error).  On AQ_VB_NEED_ALLREDUCE_MAIN / _ELBO the caller must SUM-all-reduce the
+ * corresponding device buffer (aq_vb_reduce_ptr) across processes on the same stream order
+ * (the library issues all work on the legacy default stream) and call aq_vb_advance again.
+ * With world_size == 1 the codes may simply be ignored (aq_vb_run does that). */
+#define AQ_VB_DONE 0
+#define AQ_VB_NEED_ALLREDUCE_MAIN 1
+#define AQ_VB_NEED_ALLREDUCE_ELBO 2
+int aq_vb_advance(aq_vb_handle h);
+/* which: 0 = main payload (aq_vb_reduce_len doubles), 1 = ELBO payload (8 doubles). */
+double *aq_vb_reduce_ptr(aq_vb_handle h, int32_t which);
+
+/* Single-process convenience: loops aq_vb_advance until AQ_VB_DONE (world_size must be 1). */
+int aq_vb_run(aq_vb_handle h);
+/* Runs at most max_sweeps further sweeps (stops earlier on convergence / maxit); world_size 1.
+ * Used by bench.py to time exactly K sweeps. */
+int aq_vb_run_sweeps(aq_vb_handle h, int32_t max_sweeps);
+
+typedef struct aq_vb_status {
+  int32_t it;            /* sweeps done                                   */
+  int32_t converged;
+  double lb_opt;         /* last evaluated ELBO (-inf if none yet)        */
+  double diff_lb;        /* |lb_opt - lb_old|                             */
+  double c;              /* inverse temperature of the NEXT sweep         */
+  int32_t annealing;
+  int32_t n_elbo;        /* number of ELBO evaluations so far             */
+  double core_ms;        /* accumulated device time of the core sweep kernel (HIP events) */
+  int32_t core_launches;
+  double sig02_inv_vb, sig2_inv_vb;
+  int32_t lentz_iters;   /* shared Lentz iteration count of the last non-annealed sweep */
+} aq_vb_status;
+int aq_vb_get_status(aq_vb_handle h, aq_vb_status *st);
+
+/* ELBO trace: up to cap (iteration, value) pairs in evaluation order; returns the count. */
+int32_t aq_vb_get_elbo_trace(aq_vb_handle h, int32_t *it_out, double *lb_out, int32_t cap);
+
+/* Copy results to host buffers (any pointer may be NULL to skip).  Shapes as the reference's
+ * return list (R/atlasqtl_global_local_core.R:406-428): p x q column-major matrices, p / q vectors. */
+int aq_vb_get_result(aq_vb_handle h, double *beta_vb, double *gam_vb, double *mu_beta_vb, double *theta_vb,
+                     double *zeta_vb, double *lam2_inv_vb, double *sig2_theta_vb, double *tau_vb,
+                     double *sig2_beta_vb);
+
+/* ------------------------------------------------------------------------------------------
+ * Test hooks for the fp64 special functions the path uses (host evaluation of the same
+ * header the kernels compile): which = 0 log_ndtr, 1 digamma, 2 expint_E1 (x<=1),
+ * 3 gamma_inc_upper(a=x2, x), 4 sigmoid_neg.  Evaluates elementwise into out.
+ * ---------------------------------------------------------------------------------------- */
+int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len);
+/* exp(x) E1(x) for a vector with the reference's shared Lentz stopping rule (R/utils.R:380-423);
+ * host evaluation; writes the shared iteration count to *iters. */
+int aq_q_approx_vec(const double *x, double *out, int64_t len, int32_t *iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATLASQTL_HIP_H_ */
