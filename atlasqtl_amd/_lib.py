@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libatlasqtl_hip.so")
+LIB_PATH = os.environ.get("AQ_LIB", os.path.join(_HERE, "libatlasqtl_hip.so"))
 
 AQ_OK = 0
 AQ_VB_DONE = 0

@@ -29,6 +29,13 @@
 #include <hip/hip_runtime.h>
 #include "aq_special.h"
 
+#ifndef AQ_DIAG
+#define AQ_DIAG 0      // timing diagnostics only (wrong results): 1 = skip the sequential pass, 2 = skip the MFMAs
+#endif
+#ifndef AQ_USE_DMA
+#define AQ_USE_DMA 0   // operand stream through an LDS-DMA ring (1) or register prefetch one tile ahead (0)
+#endif
+
 typedef double aq_d4 __attribute__((ext_vector_type(4)));
 
 struct AqCoreArgs {
@@ -56,7 +63,34 @@ struct AqCoreArgs {
 __device__ __forceinline__ aq_d4 aq_mfma(double a, double b, aq_d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ int aq_drow(int dmode, int reg, int g) { return dmode ? (4 * g + reg) : (4 * reg + g); }
+// Workgroup barrier that waits for this wave's LDS traffic only: global loads issued before it
+// (operand prefetch, staging) stay in flight across it.  __syncthreads() would drain vmcnt too.
+__device__ __forceinline__ void aq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at a
+// wave-uniform base (global_load_lds_dwordx4); no VGPR destination, counted in vmcnt.
+__device__ __forceinline__ void aq_dma16(const double2 *gsrc, double2 *ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+}
+// 16-byte LDS read the compiler cannot see (it would otherwise drain vmcnt before any LDS read
+// while LDS-DMA pieces are pending).  The caller waits lgkmcnt(0) before using the value.
+__device__ __forceinline__ double2 aq_lds_read16_raw(const double2 *p) {
+  double2 v;
+  unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) double2 *)p;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+// wait until at most `groups` DMA groups (4 pieces each) issued after the one needed are outstanding;
+// the argument folds to a constant in the unrolled tile loop
+__device__ __forceinline__ void aq_wait_vm_groups(int groups) {
+  switch (groups) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
+}
+__device__ __forceinline__ int aq_drow(int dmode, int reg, int g) { return (dmode ? 1 : 4) * reg + (dmode ? 4 : 1) * g; }
 
 // NT: 16-sample residual tiles per wave; NW: waves per workgroup; TT: 16-trait tiles per workgroup.
 template <int NT, int NW, int TT>
@@ -77,8 +111,13 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
   __shared__ double Lm1[TT][256];      // old m1 = gam*mu
   __shared__ double LG[512];           // Gram block [16][32]: row j holds G[j][0..15] then 16 zeros
   __shared__ double Lgam[TT][256], Lmu[TT][256], Ldel[TT][256];
-  __shared__ double Lred[4][TT][256];
+  __shared__ double Lred[4][TT][256];   // per-thread running column sums (gam, m2, beta^2, gam*b)
+  __shared__ double LB[TT][256];        // slope b of Z for the block
   __shared__ double Lrn[NW * 4][TT][16];
+  // per-wave operand ring, D slots of one residual-tile step: [XU h0, XU h1, XA h0, XA h1] x 64 lanes x 16 B
+  // (TT == 1 runs two workgroups per CU: 3 slots keep two of them inside the 160 KiB of LDS)
+  constexpr int D = (NT < 4) ? 2 : (TT == 1 ? (NW == 4 ? 3 : 2) : 4);
+  __shared__ double2 Xring[AQ_USE_DMA ? NW : 1][AQ_USE_DMA ? D : 1][4][64];
 
   // ---- residual tiles into registers: Rr[tt][t][r] <-> sample 16*(w*NT+t) + drow(r,g), trait col
   aq_d4 Rr[TT][NT];
@@ -100,12 +139,12 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
   const double2 *XUw = a.XU + (size_t)(w * NT) * 128 + lane;
 
   // helper-thread state: entry (hj, hk) of each of the TT tiles
-  double sum_g[TT], sum_m2[TT], sum_b2[TT], sum_gb[TT], sig2b_k[TT];
+  double sig2b_k[TT];
   bool kvalid[TT], tvalid[TT];
   size_t tbase[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; tt++) {
-    sum_g[tt] = sum_m2[tt] = sum_b2[tt] = sum_gb[tt] = 0.0;
+    if (helper) Lred[0][tt][tid] = Lred[1][tt][tid] = Lred[2][tt][tid] = Lred[3][tt][tid] = 0.0;
     tvalid[tt] = (tile0 + tt) < a.ntile;
     int kk = (tile0 + tt) * 16 + hk;
     kvalid[tt] = tvalid[tt] && kk < a.q;
@@ -125,9 +164,9 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
           double be = gm * mu;                                // update_beta_vb_, R/update_vb.R:17
           Ldel[tt][tid] = be;
           if (kvalid[tt] && (16 * b + hj) < a.p) {
-            sum_g[tt] += gm;
-            sum_m2[tt] += (mu * mu + sig2b_k[tt]) * gm;       // update_m2_beta_ with the initial sig2_beta_vb, :113
-            sum_b2[tt] += be * be;
+            Lred[0][tt][tid] += gm;
+            Lred[1][tt][tid] += (mu * mu + sig2b_k[tt]) * gm;   // update_m2_beta_ with the initial sig2_beta_vb, :113
+            Lred[2][tt][tid] += be * be;
           }
         }
       }
@@ -149,20 +188,37 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
         for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(u1.x, nd[tt][2], Rr[tt][t]);
 #pragma unroll
         for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(u1.y, nd[tt][3], Rr[tt][t]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
     }
   } else {
     // ---------------- full sweep ------------------------------------------------
-    // helper threads stage everything of block b that does not depend on the recursion
-    auto stage = [&](int b) {
+    // helper threads stage everything of block b that does not depend on the recursion:
+    // global loads are issued a whole MFMA phase ahead (stage_load) and written to LDS
+    // after it (stage_commit), so their latency never sits on the block's critical path.
+    double st_A[TT], st_g[TT], st_m[TT], st_B[TT], st_G = 0.0;
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++) st_A[tt] = st_g[tt] = st_m[tt] = st_B[tt] = 0.0;
+    auto stage_load = [&](int b) {
 #pragma unroll
       for (int tt = 0; tt < TT; tt++) {
         size_t off = tbase[tt] + (size_t)(16 * b) * 16 + tid;
-        LA[tt][tid] = a.Aarr[off];
-        Lm1[tt][tid] = a.gam[off] * a.mu[off];
+        st_A[tt] = a.Aarr[off];
+        st_g[tt] = a.gam[off];
+        st_m[tt] = a.mu[off];
+        st_B[tt] = a.Barr[off];
       }
-      LG[hj * 32 + hk] = a.G[(size_t)b * 256 + tid];
+      st_G = a.G[(size_t)b * 256 + tid];
+    };
+    auto stage_commit = [&]() {
+#pragma unroll
+      for (int tt = 0; tt < TT; tt++) {
+        LA[tt][tid] = st_A[tt];
+        Lm1[tt][tid] = st_g[tt] * st_m[tt];
+        LB[tt][tid] = st_B[tt];
+      }
+      LG[hj * 32 + hk] = st_G;
     };
     aq_d4 acc[TT];
 #pragma unroll
@@ -180,27 +236,38 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
         for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(a1.x, Rr[tt][t][2], acc[tt]);
 #pragma unroll
         for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(a1.y, Rr[tt][t][3], acc[tt]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (helper) stage(0);
+    // operand stream: step (bb, t) = XU tile t of block bb (update) + XA tile t of block bb+1 (next S)
+    auto dma_step = [&](int bb, int t, int slot) {
+      const double2 *xu = XUw + ((size_t)bb * NTT + t) * 128;
+      const int bn = (bb + 1 < a.nb) ? bb + 1 : bb;
+      const double2 *xa = XAw + ((size_t)bn * NTT + t) * 128;
+      aq_dma16(xu, &Xring[w][slot][0][0]);
+      aq_dma16(xu + 64, &Xring[w][slot][1][0]);
+      aq_dma16(xa, &Xring[w][slot][2][0]);
+      aq_dma16(xa + 64, &Xring[w][slot][3][0]);
+    };
+    if (helper) { stage_load(0); stage_commit(); }
 
     for (int b = 0; b < a.nb; b++) {
       const bool more = (b + 1 < a.nb);
-      const double2 *xu = XUw + (size_t)b * NTT * 128;
-      const double2 *xa = XAw + (size_t)(more ? b + 1 : b) * NTT * 128;
+      // the staging loads of block b+1 stay in flight across the sequential pass
+      if (helper && more) stage_load(b + 1);
       // partial S of this wave -> LDS
 #pragma unroll
       for (int tt = 0; tt < TT; tt++)
 #pragma unroll
         for (int i = 0; i < 4; i++) Sp[w][tt][aq_drow(a.dmode, i, g) * 16 + col] = acc[tt][i];
-      __syncthreads();
+      aq_lds_barrier();
 
       // ---- sequential pass over the 16 SNPs of the block, lane = trait (wave 0) ----
-      if (w == 0 && lane < NTR) {
+      if (w == 0 && lane < NTR && !(AQ_DIAG & 1)) {
         const int rt = lane >> 4;                          // tile of this lane's trait
         const int kk = (tile0 + rt < a.ntile ? tile0 + rt : 0) * 16 + col;
         const double rc_coef = a.coef[kk];
-        const double rc_inv2s = a.inv2s[kk];
+        const double rc_cinv2s = a.c * a.inv2s[kk];
         const double rc_cst = a.cst[kk];
         // S[0] is always the SNP being visited: after each step the vector shifts down by one
         // while the in-block Gram correction is applied (rows past the block read the zero pad).
@@ -212,29 +279,34 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
           for (int ww = 1; ww < NW; ww++) s += Sp[ww][rt][j * 16 + col];
           S[j] = s;
         }
-        double m1o = Lm1[rt][col], Aj = LA[rt][col], dj = LG[0];
+        double m1o = Lm1[rt][col], cA = a.c * (LA[rt][col] + rc_cst), dj = LG[0];
 #pragma unroll 1
         for (int j = 0; j < 16; j++) {
-          double gc[15];
-#pragma unroll
-          for (int i = 0; i < 15; i++) gc[i] = LG[j * 32 + j + 1 + i];    // G[j+1+i][j] (symmetric), 0 past the block
           const int jn = (j + 1) & 15;
-          double m1o_n = Lm1[rt][jn * 16 + col], A_n = LA[rt][jn * 16 + col], d_n = LG[jn * 33];
+          double m1o_n = Lm1[rt][jn * 16 + col], cA_n = a.c * (LA[rt][jn * 16 + col] + rc_cst), d_n = LG[jn * 33];
           double s = S[0] + m1o * dj;                       // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1*cp_X(j,j))   :71
           double mu = rc_coef * s;                          // :73
-          double x = a.c * (Aj - mu * mu * rc_inv2s + rc_cst);   // :75-77
+          double x = cA - (mu * mu) * rc_cinv2s;            // c*(log(1-Phi) - log Phi - mu^2/(2 sig2) + cst)   :75-77
           double gm = aq_sigmoid_neg(x);
-          double m1 = gm * mu;                              // :79
-          double dl = m1 - m1o;
+          double dl = gm * mu - m1o;                        // m1 - m1_old, m1 = gam*mu   :79
+          // in-block part of :81: S shifts down by one; G[j+1+i][j] (symmetric) reads the zero pad past the block
 #pragma unroll
-          for (int i = 0; i < 15; i++) S[i] = S[i + 1] - gc[i] * dl;      // in-block part of :81
+          for (int i0 = 0; i0 < 15; i0 += 8) {
+            double gc[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) gc[i] = (i0 + i < 15) ? LG[j * 32 + j + 1 + i0 + i] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+              if (i0 + i < 15) S[i0 + i] = S[i0 + i + 1] - gc[i] * dl;
+            __builtin_amdgcn_sched_barrier(0);
+          }
           Lgam[rt][j * 16 + col] = gm;
           Lmu[rt][j * 16 + col] = mu;
           Ldel[rt][j * 16 + col] = dl;
-          m1o = m1o_n; Aj = A_n; dj = d_n;
+          m1o = m1o_n; cA = cA_n; dj = d_n;
         }
       }
-      __syncthreads();
+      aq_lds_barrier();
 
       // ---- finalize block b (helper threads): stores and column/row sums ----
       if (helper) {
@@ -249,11 +321,11 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
             a.mu[off] = mu;
             if (kvalid[tt] && j < a.p) {
               double be = gm * mu;
-              gb = gm * a.Barr[off];
-              sum_g[tt] += gm;
-              sum_m2[tt] += (mu * mu + sig2b_k[tt]) * gm;   // update_m2_beta_, R/update_vb.R:19-31
-              sum_b2[tt] += be * be;
-              sum_gb[tt] += gb;
+              gb = gm * LB[tt][tid];
+              Lred[0][tt][tid] += gm;
+              Lred[1][tt][tid] += (mu * mu + sig2b_k[tt]) * gm;   // update_m2_beta_, R/update_vb.R:19-31
+              Lred[2][tt][tid] += be * be;
+              Lred[3][tt][tid] += gb;
             }
           }
           // row sum over the 16 traits of this tile (16-lane groups are aligned)
@@ -273,8 +345,10 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
         for (int s = 0; s < 4; s++) nd[tt][s] = -Ldel[tt][(4 * s + g) * 16 + col];
 #pragma unroll
       for (int tt = 0; tt < TT; tt++) acc[tt] = (aq_d4){0, 0, 0, 0};
+      constexpr bool do_mfma = !(AQ_DIAG & 2);
+      const double2 *xu = XUw + (size_t)b * NTT * 128;
+      const double2 *xa = XAw + (size_t)(more ? b + 1 : b) * NTT * 128;
       double2 cu0 = xu[0], cu1 = xu[64], ca0 = xa[0], ca1 = xa[64];
-      double2 pa0 = ca0, pa1 = ca1;
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         double2 nu0, nu1, na0, na1;
@@ -282,38 +356,29 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
           nu0 = xu[(t + 1) * 128]; nu1 = xu[(t + 1) * 128 + 64];
           na0 = xa[(t + 1) * 128]; na1 = xa[(t + 1) * 128 + 64];
         }
+        if (do_mfma) {
 #pragma unroll
-        for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(cu0.x, nd[tt][0], Rr[tt][t]);
+          for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(cu0.x, nd[tt][0], Rr[tt][t]);
 #pragma unroll
-        for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(cu0.y, nd[tt][1], Rr[tt][t]);
+          for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(cu0.y, nd[tt][1], Rr[tt][t]);
 #pragma unroll
-        for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(cu1.x, nd[tt][2], Rr[tt][t]);
+          for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(cu1.x, nd[tt][2], Rr[tt][t]);
 #pragma unroll
-        for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(cu1.y, nd[tt][3], Rr[tt][t]);
-        if (t > 0) {
+          for (int tt = 0; tt < TT; tt++) Rr[tt][t] = aq_mfma(cu1.y, nd[tt][3], Rr[tt][t]);
 #pragma unroll
-          for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(pa0.x, Rr[tt][t - 1][0], acc[tt]);
+          for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(ca0.x, Rr[tt][t][0], acc[tt]);
 #pragma unroll
-          for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(pa0.y, Rr[tt][t - 1][1], acc[tt]);
+          for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(ca0.y, Rr[tt][t][1], acc[tt]);
 #pragma unroll
-          for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(pa1.x, Rr[tt][t - 1][2], acc[tt]);
+          for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(ca1.x, Rr[tt][t][2], acc[tt]);
 #pragma unroll
-          for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(pa1.y, Rr[tt][t - 1][3], acc[tt]);
+          for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(ca1.y, Rr[tt][t][3], acc[tt]);
         }
-        pa0 = ca0; pa1 = ca1;
         if (t + 1 < NT) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);   // keep later tiles' operand loads from being hoisted (VGPR budget)
       }
-#pragma unroll
-      for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(pa0.x, Rr[tt][NT - 1][0], acc[tt]);
-#pragma unroll
-      for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(pa0.y, Rr[tt][NT - 1][1], acc[tt]);
-#pragma unroll
-      for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(pa1.x, Rr[tt][NT - 1][2], acc[tt]);
-#pragma unroll
-      for (int tt = 0; tt < TT; tt++) acc[tt] = aq_mfma(pa1.y, Rr[tt][NT - 1][3], acc[tt]);
-      // ---- stage block b+1 (helper threads) ----
-      if (helper && more) stage(b + 1);
+      // ---- block b+1's staged values -> LDS (helper threads) ----
+      if (helper && more) stage_commit();
     }
   }
 
@@ -335,12 +400,6 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
       }
     }
     Lrn[w * 4 + g][tt][col] = rn;
-    if (helper) {
-      Lred[0][tt][tid] = sum_g[tt];
-      Lred[1][tt][tid] = sum_m2[tt];
-      Lred[2][tt][tid] = sum_b2[tt];
-      Lred[3][tt][tid] = sum_gb[tt];
-    }
   }
   __syncthreads();
   if (tid < NTR) {
