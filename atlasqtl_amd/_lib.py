@@ -32,7 +32,7 @@ class AqVbProblem(C.Structure):
         ("has_anneal", C.c_int32), ("anneal", C.c_double * 3), ("tol", C.c_double), ("maxit", C.c_int32),
         ("thinned_elbo_eval", C.c_int32), ("debug", C.c_int32),
         ("device", C.c_int32), ("world_size", C.c_int32),
-        ("ext_reduce_main", C.c_void_p), ("ext_reduce_elbo", C.c_void_p),
+        ("ext_reduce_main", C.c_void_p), ("ext_reduce_elbo", C.c_void_p), ("init_on_device", C.c_int32),
     ]
 
 
@@ -59,6 +59,7 @@ SYMBOLS = {
     "aq_vb_destroy": (None, [C.c_void_p]),
     "aq_vb_advance": (C.c_int, [C.c_void_p]),
     "aq_vb_reduce_ptr": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "aq_vb_set_sweep_budget": (C.c_int, [C.c_void_p, C.c_int32]),
     "aq_vb_run": (C.c_int, [C.c_void_p]),
     "aq_vb_run_sweeps": (C.c_int, [C.c_void_p, C.c_int32]),
     "aq_vb_get_status": (C.c_int, [C.c_void_p, C.POINTER(AqVbStatus)]),

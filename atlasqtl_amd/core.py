@@ -146,8 +146,21 @@ class VbRun:
         pr.nu = float(list_hyper["nu"]); pr.rho = float(list_hyper["rho"]); pr.t02 = float(list_hyper["t02"])
         pr.eta = vec(list_hyper["eta"], q, "eta"); pr.kappa = vec(list_hyper["kappa"], q, "kappa")
         pr.n0 = vec(list_hyper["n0"], q, "n0")
-        pr.gam_vb = mat(list_init["gam_vb"], (p, q), "gam_vb")
-        pr.mu_beta_vb = mat(list_init["mu_beta_vb"], (p, q), "mu_beta_vb")
+        g0, m0_ = list_init["gam_vb"], list_init["mu_beta_vb"]
+        if hasattr(g0, "data_ptr"):
+            # torch CUDA tensors holding the p x q matrices column-major, i.e. a contiguous (q, p) tensor
+            for tname, tt in (("gam_vb", g0), ("mu_beta_vb", m0_)):
+                if not (tt.is_cuda and tt.is_contiguous() and tuple(tt.shape) == (q, p) and str(tt.dtype) == "torch.float64"):
+                    raise ValueError(f"{tname} on device must be a contiguous float64 CUDA tensor of shape (q, p) "
+                                     "(= p x q column-major)")
+            keep += [g0, m0_]
+            pr.gam_vb = C.cast(g0.data_ptr(), _lib.dp)
+            pr.mu_beta_vb = C.cast(m0_.data_ptr(), _lib.dp)
+            pr.init_on_device = 1
+        else:
+            pr.gam_vb = mat(g0, (p, q), "gam_vb")
+            pr.mu_beta_vb = mat(m0_, (p, q), "mu_beta_vb")
+            pr.init_on_device = 0
         pr.sig02_inv_vb = float(list_init["sig02_inv_vb"])
         pr.sig2_beta_vb = vec(list_init["sig2_beta_vb"], q, "sig2_beta_vb")
         pr.sig2_theta_vb = vec(list_init["sig2_theta_vb"], p, "sig2_theta_vb")
@@ -183,7 +196,14 @@ class VbRun:
         if self.pg is None:
             return
         import torch.distributed as dist
-        dist.all_reduce(self._red if which == 0 else self._ered, op=dist.ReduceOp.SUM, group=self.pg)
+        t = self._red if which == 0 else self._ered
+        if dist.get_backend(self.pg) == "gloo":
+            # CPU-staged exchange (tests on a one-GPU box); RCCL reduces the device buffer in place
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
     def advance_until_done(self):
         """aq_vb_advance loop; all-reduces the payloads across the process group."""
@@ -204,8 +224,13 @@ class VbRun:
         return self
 
     def run_sweeps(self, k):
-        """Run at most k further sweeps (single process only; bench.py's timed region)."""
-        check(lib().aq_vb_run_sweeps(self.h, int(k)), "aq_vb_run_sweeps")
+        """Run at most k further sweeps (bench.py's timed region); works with and without a process group."""
+        if self.pg is None:
+            check(lib().aq_vb_run_sweeps(self.h, int(k)), "aq_vb_run_sweeps")
+            return
+        check(lib().aq_vb_set_sweep_budget(self.h, int(k)), "aq_vb_set_sweep_budget")
+        self.advance_until_done()
+        check(lib().aq_vb_set_sweep_budget(self.h, -1), "aq_vb_set_sweep_budget")
 
     def status(self):
         st = AqVbStatus()

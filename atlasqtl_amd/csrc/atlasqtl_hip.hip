@@ -154,6 +154,7 @@ struct aq_vb {
   double core_ms_acc = 0.0;
   int core_launches = 0;
   bool failed = false;
+  int budget = -1;
 };
 
 static void aq_free_all(aq_vb *s) {
@@ -357,7 +358,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     AQ_HIPF(hipFree(Xd));
   }
   {
-    size_t big = std::max((size_t)pr->p * pr->q, nq);
+    size_t big = pr->init_on_device ? nq : std::max((size_t)pr->p * pr->q, nq);
     double *stage = nullptr;
     AQ_HIPF(hipMalloc((void **)&stage, big * sizeof(double)));
     AQ_HIPF(hipMemcpy(stage, pr->Y, nq * sizeof(double), hipMemcpyHostToDevice));
@@ -365,12 +366,19 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
                        s->n, s->q, s->n_pad, 1);
     AQ_HIPF(hipDeviceSynchronize());
     size_t pq = (size_t)pr->p * pr->q;
-    AQ_HIPF(hipMemcpy(stage, pr->gam_vb, pq * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->p_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->gam,
+    const double *gsrc = pr->gam_vb, *msrc = pr->mu_beta_vb;
+    if (!pr->init_on_device) {
+      AQ_HIPF(hipMemcpy(stage, pr->gam_vb, pq * sizeof(double), hipMemcpyHostToDevice));
+      gsrc = stage;
+    }
+    hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->p_pad + 63) / 64, s->ntile), dim3(256), 0, 0, gsrc, s->gam,
                        s->p, s->q, s->p_pad, 0);
     AQ_HIPF(hipDeviceSynchronize());
-    AQ_HIPF(hipMemcpy(stage, pr->mu_beta_vb, pq * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->p_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->mu,
+    if (!pr->init_on_device) {
+      AQ_HIPF(hipMemcpy(stage, pr->mu_beta_vb, pq * sizeof(double), hipMemcpyHostToDevice));
+      msrc = stage;
+    }
+    hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->p_pad + 63) / 64, s->ntile), dim3(256), 0, 0, msrc, s->mu,
                        s->p, s->q, s->p_pad, 0);
     AQ_HIPF(hipDeviceSynchronize());
     AQ_HIPF(hipFree(stage));
@@ -581,8 +589,13 @@ static int aq_advance_impl(aq_vb *s, int *sweeps_budget) {
 
 extern "C" int aq_vb_advance(aq_vb_handle h) {
   if (!h) return -aq_fail(AQ_ERR_ARG, "NULL handle");
-  int rc = aq_advance_impl(h, nullptr);
+  int rc = aq_advance_impl(h, h->budget >= 0 ? &h->budget : nullptr);
   return rc;
+}
+extern "C" int aq_vb_set_sweep_budget(aq_vb_handle h, int32_t sweeps) {
+  if (!h) return aq_fail(AQ_ERR_ARG, "NULL handle");
+  h->budget = sweeps < 0 ? -1 : sweeps;
+  return AQ_OK;
 }
 
 static int aq_run_impl(aq_vb *s, int *budget) {

@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- VB sweeps/s of the MI355X-native atlasqtl hot path.
+
+Contract (see the task description): ``python bench.py --gpus N --steps K --warmup W``;
+for N > 1 it is launched by ``python -m torch.distributed.run --nproc-per-node N``
+(one rank per GPU, RCCL).  A *step* is one VB sweep = steps S1-S22 of SURVEY.md
+section 3.2 (pre-pass, spike-and-slab core sweep, horseshoe/probit updates, and the
+scheduled ELBO evaluations) on synthetic data of BASELINE.json's size:
+n = 1000 samples, p = 50 000 SNPs, q = 10 000 traits, annealing schedule on.
+W warm-up sweeps (default 10: the whole annealing ladder), then exactly K timed sweeps
+between barrier + synchronize; time = max over ranks; rank 0 prints ONE JSON line.
+
+With N > 1 the trait axis is sharded (q/N traits per rank, same total problem: strong
+scaling); the only data-path exchange is one all-reduce of p+8 doubles per sweep (+ 8
+doubles on ELBO sweeps).
+
+Environment overrides for quick checks: AQ_BENCH_N / AQ_BENCH_P / AQ_BENCH_Q.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# FP64 peaks used for the roofline: AMD's public MI355X figure (vector = matrix FP64) and the
+# v_mfma_f64_16x16x4_f64 rate measured on this pool with tools/microbench/f64_peak.hip
+# (MI355X_MICROARCH.md has no FP64 row) -- see DESIGN.md section 6.
+PEAK_FP64_SPEC_TFLOPS = 78.6
+PEAK_FP64_MFMA_MEASURED_TFLOPS = 47.7
+
+
+def build_problem(n, p, q_total, k0, k1, device, seed=123):
+    """Synthetic hotspot-QTL data (shape of R/atlasqtl.R:125-157), identical for every
+    rank count: X, the q-vectors and Y are generated in full from fixed seeds and sliced;
+    the p x q initial values are generated on the GPU per 16-trait tile from a seed that
+    depends only on the global tile index."""
+    import torch
+    from atlasqtl_amd import hyper_init as H
+    from atlasqtl_amd.prepare import scale_columns
+
+    rng = np.random.default_rng(seed)
+    maf = rng.uniform(0.05, 0.5, size=p)
+    X = rng.binomial(2, maf[None, :], size=(n, p)).astype(np.float64)
+    X = scale_columns(X)
+    bad = ~np.isfinite(X).all(axis=0)
+    if bad.any():                       # a constant column (very unlikely at n = 1000): make it a fresh SNP
+        X[:, bad] = scale_columns(rng.binomial(2, 0.3, size=(n, int(bad.sum()))).astype(np.float64) + 1e-9 *
+                                  rng.normal(size=(n, int(bad.sum()))))
+    p_act, q_act = 40, max(16, q_total // 4)
+    act_x = np.sort(rng.choice(p, size=p_act, replace=False))
+    act_y = np.sort(rng.choice(q_total, size=q_act, replace=False))
+    beta = np.where(rng.random((p_act, q_act)) < 0.2, rng.normal(size=(p_act, q_act)), 0.0) * 0.3
+    Y = rng.normal(size=(n, q_total))
+    Y[:, act_y] += X[:, act_x] @ beta
+    Y -= Y.mean(axis=0)
+    p0 = (5.0, 25.0)
+    lh = H.auto_set_hyper_(Y, p, p0)
+    irng = np.random.default_rng(seed + 333)
+    t02, n0 = lh["t02"], float(lh["n0"][0])
+    tau = 1.0 / float(np.median(Y.var(axis=0, ddof=1)))
+    sig02_inv = float(irng.gamma(shape=max(p, q_total)))
+    li = dict(sig02_inv_vb=sig02_inv,
+              sig2_beta_vb=1.0 / irng.gamma(shape=2.0, scale=1e-2 * tau, size=q_total),
+              sig2_theta_vb=1.0 / (q_total + irng.gamma(shape=sig02_inv * q_total, size=p)),
+              tau_vb=np.full(q_total, tau),
+              theta_vb=irng.normal(scale=1.0 / np.sqrt(sig02_inv * q_total), size=p),
+              zeta_vb=irng.normal(loc=n0, scale=np.sqrt(t02), size=q_total))
+    sl = slice(k0, k1)
+    lh_loc = dict(lh)
+    for key in ("eta", "kappa", "n0"):
+        lh_loc[key] = np.ascontiguousarray(lh[key][sl])
+    li_loc = dict(li)
+    for key in ("sig2_beta_vb", "tau_vb", "zeta_vb"):
+        li_loc[key] = np.ascontiguousarray(li[key][sl])
+    # p x q initial values on the device, (q_loc, p) contiguous == p x q_loc column-major
+    q_loc = k1 - k0
+    dev = torch.device("cuda", device)
+    gam = torch.empty((q_loc, p), dtype=torch.float64, device=dev)
+    mu = torch.empty((q_loc, p), dtype=torch.float64, device=dev)
+    gen = torch.Generator(device=dev)
+    for t0 in range(k0 - k0 % 16, k1, 16):
+        gen.manual_seed(seed * 1000003 + t0 // 16)
+        z = torch.randn((2, 16, p), dtype=torch.float64, device=dev, generator=gen)
+        lo, hi = max(t0, k0), min(t0 + 16, k1)
+        gam[lo - k0:hi - k0] = torch.special.ndtr(n0 + (1e-4 + t02) * z[0, lo - t0:hi - t0])   # R/set_hyper_init.R:385
+        mu[lo - k0:hi - k0] = z[1, lo - t0:hi - t0]                                           # :387
+    li_loc["gam_vb"], li_loc["mu_beta_vb"] = gam, mu
+    return np.asfortranarray(X), np.asfortranarray(Y[:, sl]), lh_loc, li_loc
+
+
+def cpu_baseline(n, p, q_total, seed=7, budget_s=12.0):
+    """The oracle's n-space port of src/coreLoop.cpp:38-86 (oracle/core_loop_oracle.c, gcc -O2,
+    one thread) timed on a trait sub-sample at full n and p, scaled by q/q_sub (traits are
+    independent and equal-cost).  Covers step S9 only, i.e. it flatters the CPU."""
+    from oracle import atlasqtl_oracle as O
+    rng = np.random.default_rng(seed)
+    X = np.asfortranarray(rng.normal(size=(n, p)))
+    q_sub = 4
+
+    def once(qs):
+        R = np.asfortranarray(rng.normal(size=(n, qs)))
+        gam = np.asfortranarray(rng.uniform(0.001, 0.01, size=(p, qs)))
+        mu = np.asfortranarray(rng.normal(size=(p, qs)) * 0.01)
+        m1 = np.asfortranarray(gam * mu)
+        lP = np.asfortranarray(np.full((p, qs), -6.0))
+        l1 = np.asfortranarray(np.full((p, qs), -0.0025))
+        t0 = time.perf_counter()
+        O.nspace_loop(X, R, None, np.full(p, n - 1.0), gam, lP, l1, -0.3, np.zeros(qs), m1, mu, np.full(qs, 1e-3),
+                      np.ones(qs), 1.0)
+        return time.perf_counter() - t0
+
+    t = once(q_sub)
+    per_trait = t / q_sub
+    extra = int(max(0, min(4096, (budget_s - t) / max(per_trait, 1e-9))))
+    if extra >= 4:
+        t2 = once(extra)
+        per_trait = (t + t2) / (q_sub + extra)
+        q_sub += extra
+    sweep_s = per_trait * q_total
+    return {"value": 1.0 / sweep_s, "unit": "sweeps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle n-space core loop (step S9 only), {q_sub} of {q_total} traits at full n={n}, p={p}, "
+                      f"{per_trait * q_sub:.1f} s measured, scaled by q/q_sub"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from atlasqtl_amd.core import VbRun
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        pg = dist.group.WORLD
+
+    n = int(os.environ.get("AQ_BENCH_N", 1000))
+    p = int(os.environ.get("AQ_BENCH_P", 50000))
+    q = int(os.environ.get("AQ_BENCH_Q", 10000))
+    # shard traits in whole 16-trait tiles
+    tiles = (q + 15) // 16
+    t_lo = (tiles * rank) // world
+    t_hi = (tiles * (rank + 1)) // world
+    k0, k1 = min(q, 16 * t_lo), min(q, 16 * t_hi)
+
+    t_setup = time.time()
+    X, Y, lh, li = build_problem(n, p, q, k0, k1, local_rank)
+    anneal = (1, 2, 10)
+    run = VbRun(Y, X, lh, li, anneal, tol=1e-12, maxit=args.warmup + args.steps + 5, thinned_elbo_eval=True,
+                debug=False, device=local_rank, q_total=q, process_group=pg)
+    del li
+    torch.cuda.empty_cache()
+    t_setup = time.time() - t_setup
+
+    def sync():
+        torch.cuda.synchronize()
+        if pg is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run.run_sweeps(args.warmup)
+    st0 = run.status()
+    sync()
+    t0 = time.perf_counter()
+    run.run_sweeps(args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    if pg is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    st1 = run.status()
+    sweeps_done = st1["it"] - st0["it"]
+    assert sweeps_done == args.steps, (sweeps_done, args.steps)
+
+    if rank == 0:
+        core_ms = (st1["core_ms"] - st0["core_ms"]) / max(st1["core_launches"] - st0["core_launches"], 1)
+        q_loc = k1 - k0
+        flop_per_launch = 4.0 * n * p * q_loc                  # W_f = 4 n p q (this rank's traits)
+        achieved = flop_per_launch / (core_ms * 1e-3) / 1e12
+        out = {
+            "metric": "VB sweeps/sec", "value": args.steps / dt, "unit": "sweeps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"atlasqtl VB sweep (S1-S22 incl. scheduled ELBO), n={n} p={p} q={q}, "
+                                   f"anneal=(1,2,10) on, horseshoe global-local, sweeps {st0['it'] + 1}-{st1['it']}",
+                       "n": n, "p": p, "q": q, "q_per_gpu": q_loc, "parallelism": f"trait-sharded x{world}",
+                       "elbo_evals_in_timed_region": st1["n_elbo"] - st0["n_elbo"], "setup_s": round(t_setup, 1)},
+            "roofline": {"bound": "mfma", "kernel": "aq_core_sweep_kernel", "achieved": achieved,
+                         "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,
+                         "traffic": None, "peak_measured_mfma_f64": PEAK_FP64_MFMA_MEASURED_TFLOPS,
+                         "frac_of_measured_mfma_peak": achieved / PEAK_FP64_MFMA_MEASURED_TFLOPS,
+                         "kernel_ms_avg": core_ms, "flop_per_launch": flop_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, p, q)
+            except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+                out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": 1, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    run.close()
+    if pg is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

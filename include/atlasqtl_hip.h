@@ -105,6 +105,8 @@ typedef struct aq_vb_problem {
                                   caller (e.g. a torch tensor) used as the all-reduce payload; NULL =
                                   the library allocates it                                            */
   double *ext_reduce_elbo;     /* optional DEVICE buffer of 8 doubles, same purpose                   */
+  int32_t init_on_device;      /* 1: gam_vb and mu_beta_vb are DEVICE pointers (p x q column-major) on
+                                  `device`; avoids staging 2 x 8pq bytes through the host              */
 } aq_vb_problem;
 
 /* Length (in doubles) of the main all-reduce payload for a problem with p predictors:
@@ -126,6 +128,11 @@ void aq_vb_destroy(aq_vb_handle h);
 int aq_vb_advance(aq_vb_handle h);
 /* which: 0 = main payload (aq_vb_reduce_len doubles), 1 = ELBO payload (8 doubles). */
 double *aq_vb_reduce_ptr(aq_vb_handle h, int32_t which);
+
+/* Limit the number of further sweeps aq_vb_advance may start (-1 = no limit); when the budget is
+ * used up aq_vb_advance returns AQ_VB_DONE although the run is not over, and a later budget resumes it.
+ * bench.py uses it to time exactly K sweeps on N processes. */
+int aq_vb_set_sweep_budget(aq_vb_handle h, int32_t sweeps);
 
 /* Single-process convenience: loops aq_vb_advance until AQ_VB_DONE (world_size must be 1). */
 int aq_vb_run(aq_vb_handle h);
