@@ -1,0 +1,81 @@
+"""GPU: the real q-sharded HIP path on ONE box -- two processes share cuda:0, each holds half of the
+traits, the all-reduce payloads travel through gloo (CPU-staged; RCCL needs one GPU per rank) --
+against the single-process HIP run and the golden fixture."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import atlasqtl_amd as A
+    from tests.util import make_problem
+    prob = make_problem(200, 130, 49, p_act=10, prob_assoc=0.3)
+    q = 49
+    k0, k1 = (0, 32) if rank == 0 else (32, 49)
+    lh, li = dict(prob["list_hyper"]), dict(prob["list_init"])
+    for k in ("eta", "kappa", "n0"):
+        lh[k] = np.asarray(lh[k])[k0:k1]
+    for k in ("sig2_beta_vb", "tau_vb", "zeta_vb"):
+        li[k] = np.asarray(li[k])[k0:k1]
+    for k in ("gam_vb", "mu_beta_vb"):
+        li[k] = np.asarray(li[k])[:, k0:k1]
+    out = A.atlasqtl_global_local_core_(prob["Y"][:, k0:k1], prob["X"], q, (1, 2, 10), 1, 0.1, 1000, 0, lh, li,
+                                        full_output=True, debug=True, process_group=dist.group.WORLD)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), it=out["it"], lb=out["elbo_trace"][1], gam=out["gam_vb"],
+             mu=out["mu_beta_vb"], theta=out["theta_vb"], zeta=out["zeta_vb"])
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    import atlasqtl_amd as A
+    from tests.util import make_problem
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    prob = make_problem(200, 130, 49, p_act=10, prob_assoc=0.3)
+    one = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 49, (1, 2, 10), 1, 0.1, 1000, 0, prob["list_hyper"],
+                                        prob["list_init"], full_output=True, debug=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["it"]) == int(r1["it"]) == one["it"]
+    np.testing.assert_allclose(r0["lb"], one["elbo_trace"][1], rtol=1e-10)
+    np.testing.assert_array_equal(r0["lb"], r1["lb"])
+    np.testing.assert_allclose(np.concatenate([r0["mu"], r1["mu"]], axis=1), one["mu_beta_vb"], rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(r0["theta"], one["theta_vb"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_array_equal(r0["theta"], r1["theta"])
+
+
+def test_golden_fixture_on_gpu():
+    """tests/golden/vb_toy_anneal.npz (oracle-produced, see make_golden.py) through the HIP path."""
+    import atlasqtl_amd as A
+    from tests.test_oracle import load_vb
+    for name in ("vb_toy_anneal", "vb_toy_noanneal", "vb_harmonic"):
+        z, lh, li, anneal = load_vb(name)
+        q = z["Y"].shape[1]
+        got = A.atlasqtl_global_local_core_(z["Y"], z["X"], q, anneal, 1, 0.1, 1000, 0, lh, li, full_output=True,
+                                            debug=True)
+        assert got["it"] == int(z["out_it"])
+        np.testing.assert_allclose(got["elbo_trace"][1], z["out_elbo_lb"], rtol=1e-9)
+        np.testing.assert_allclose(got["mu_beta_vb"], z["out_mu_beta_vb"], rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(got["gam_vb"], z["out_gam_vb"], atol=1e-9)
+
+
+def test_missing_y_reports_unsupported():
+    """NaN in Y: the n-space device path does not handle it yet and must say so (operator-level
+    aq_core_dual_mis_loop does)."""
+    import atlasqtl_amd as A
+    from atlasqtl_amd import _lib
+    from tests.test_oracle import load_vb
+    z, lh, li, anneal = load_vb("vb_toy_missing")
+    with pytest.raises(_lib.AtlasqtlHipError, match="missing values in Y"):
+        A.atlasqtl_global_local_core_(z["Y"], z["X"], z["Y"].shape[1], anneal, 1, 0.1, 10, 0, lh, li)

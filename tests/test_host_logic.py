@@ -1,0 +1,94 @@
+"""Host-side mirror of the reference's R pre-processing / hyper / init code (no GPU)."""
+import numpy as np
+import pytest
+
+import atlasqtl_amd as A
+from atlasqtl_amd import hyper_init as H
+from atlasqtl_amd import prepare as P
+from atlasqtl_amd import synth
+
+
+def test_scale_and_removals():
+    rng = np.random.default_rng(0)
+    X = rng.binomial(2, 0.3, size=(50, 8)).astype(float)
+    X[:, 3] = 1.0                      # constant  -> NaN after scale -> removed (R/utils.R:278)
+    X[:, 6] = X[:, 1]                  # duplicate -> removed, later one dropped (R/utils.R:307)
+    Y = rng.normal(size=(50, 4))
+    d = P.prepare_data_(Y, X, 0.1, 1000, None, 0, None, None)
+    assert d["X"].shape == (50, 6)
+    assert list(np.where(d["bool_rmvd_x"])[0]) == [3, 6]
+    assert d["rmvd_cst_x"] == ["Cov_x_4"] and d["rmvd_coll_x"] == {"Cov_x_7": "Cov_x_2"}
+    np.testing.assert_allclose((d["X"] ** 2).sum(0), 49.0)          # diag(X'X) = n - 1 (note N1)
+    np.testing.assert_allclose(d["Y"].mean(0), 0, atol=1e-14)
+
+
+def test_input_guards():
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(40, 5)); Y = rng.normal(size=(40, 3))
+    with pytest.raises(A.AtlasqtlError, match="same number of samples"):
+        P.prepare_data_(Y[:30], X, 0.1, 10, None, 0, None, None)
+    Xn = X.copy(); Xn[0, 0] = np.nan
+    with pytest.raises(A.AtlasqtlError):
+        P.prepare_data_(Y, Xn, 0.1, 10, None, 0, None, None)          # X must be NA-free (R/prepare_atlasqtl.R:19)
+    Yn = Y.copy(); Yn[:, 1] = np.nan
+    with pytest.raises(A.AtlasqtlError, match="97.5% missing"):
+        P.prepare_data_(Yn, X, 0.1, 10, None, 0, None, None)
+    with pytest.raises(A.AtlasqtlError, match="positive"):
+        P.prepare_data_(Y, X, 0.0, 10, None, 0, None, None)
+    with pytest.raises(A.AtlasqtlError, match="natural"):
+        P.prepare_data_(Y, X, 0.1, 2.5, None, 0, None, None)
+
+
+@pytest.mark.parametrize("anneal,msg", [((4, 2, 10), "spacing scheme"), ((1, 1.2, 10), "temperature very small"),
+                                        ((1, 2, 2000), "grid size very large"), ((1, 2), "anneal")])
+def test_check_annealing(anneal, msg):
+    with pytest.raises(A.AtlasqtlError, match=msg):
+        P.check_annealing_(anneal)
+    P.check_annealing_(None)
+    P.check_annealing_((2, 1.5, 3))
+
+
+def test_set_hyper_and_init_validation():
+    h = A.set_hyper(3, 5, eta=1.0, kappa=[1, 2, 3], n0=-2.0, nu=0.01, rho=1.0, t02=0.1)
+    assert h["eta"].shape == (3,) and h["m0"] == 0 and h["A2_inv"] == 1 and h.cls == "hyper"
+    with pytest.raises(A.AtlasqtlError):
+        A.set_hyper(3, 5, eta=-1.0, kappa=1.0, n0=0.0, nu=0.01, rho=1.0, t02=0.1)
+    rng = np.random.default_rng(0)
+    with pytest.raises(A.AtlasqtlError, match="between 0 and 1"):
+        A.set_init(3, 5, rng.uniform(1, 2, (5, 3)), rng.normal(size=(5, 3)), 1.0, np.ones(3), np.ones(5), np.ones(3),
+                   np.zeros(5), np.zeros(3))
+    li = A.set_init(3, 5, rng.uniform(0, 1, (5, 3)), rng.normal(size=(5, 3)), 1.0, np.ones(3), np.ones(5), np.ones(3),
+                    np.zeros(5), np.zeros(3))
+    assert li.cls == "init" and li["gam_vb"].shape == (5, 3)
+
+
+def test_auto_hyper_matches_prior_moments():
+    """t02, n0 solve E[#active] = p0[1], Var = p0[2] (R/set_hyper_init.R:161-179, R/utils.R:218-242)."""
+    Y = np.random.default_rng(0).normal(size=(80, 6))
+    h = H.auto_set_hyper_(Y, 500, (5, 25))
+    mu, t02 = h["n0"][0], h["t02"]
+    assert abs(500 * H.E_Phi_X(mu, t02) - 5) < 1e-8
+    assert abs(H.get_V_p_t(mu, t02, 500) - 25) < 1e-6
+    assert h["nu"] == 1e-2 and h["rho"] == 1 and np.all(h["kappa"] == 1)
+    with pytest.raises(A.AtlasqtlError, match="No hyperparameter values"):
+        H.auto_set_hyper_(Y, 10, (5, 1e6))
+
+
+def test_auto_init_shapes_and_seed():
+    Y = np.random.default_rng(0).normal(size=(80, 6))
+    a = H.auto_set_init_(Y, 30, (5, 25), 6, 7)
+    b = H.auto_set_init_(Y, 30, (5, 25), 6, 7)
+    assert a["gam_vb"].shape == (30, 6) and np.all((a["gam_vb"] >= 0) & (a["gam_vb"] <= 1))
+    np.testing.assert_array_equal(a["mu_beta_vb"], b["mu_beta_vb"])
+    assert a["sig2_theta_vb"].shape == (30,) and np.all(a["sig2_beta_vb"] > 0)
+
+
+def test_list_dimension_checks():
+    d = synth.simulate(60, 20, 4, p_act=3, seed=1)
+    dat = P.prepare_data_(d["Y"], d["X"], 0.1, 10, None, 0, None, None)
+    p = dat["X"].shape[1]
+    bad = A.set_hyper(5, len(dat["bool_rmvd_x"]), 1.0, 1.0, -2.0, 0.01, 1.0, 0.1)
+    with pytest.raises(A.AtlasqtlError, match=r"dimensions \(q\)"):
+        H.prepare_list_hyper_(bad, dat["Y"], p, (2, 4), dat["bool_rmvd_x"])
+    with pytest.raises(A.AtlasqtlError, match="must be an object of class"):
+        H.prepare_list_hyper_({"q_hyper": 4}, dat["Y"], p, (2, 4), dat["bool_rmvd_x"])
