@@ -42,6 +42,7 @@ struct AqCoreArgs {
   const double2 *XA;
   const double2 *XU;
   const double *G;
+  const double *Gx;      // [nb][16][16]  X_b'X_{b-1} (look-ahead kernel only)
   double *R;          // [ntile][n_pad][16]
   double *gam;        // [ntile][p_pad][16]
   double *mu;         // [ntile][p_pad][16]

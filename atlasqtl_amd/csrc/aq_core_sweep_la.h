@@ -1,0 +1,295 @@
+// aq_core_sweep_la.h -- core sweep kernel, "look-ahead" form (the one bench.py measures).
+//
+// Same arithmetic as aq_core_sweep.h (blocked Gauss-Seidel in n-space for
+// src/coreLoop.cpp:38-86), restructured so that the sequential 16-SNP pass -- a chain of
+// ~23 dependent fp64 operations per SNP that cannot be shortened -- runs CONCURRENTLY with the
+// matrix work instead of between two barriers:
+//
+//   workgroup = NWM "matrix" waves (each owns NT 16-sample tiles of the residual R_K in VGPRs)
+//             + 1 "recurrence" wave (lane = trait, owns no residual)
+//   phase b (one barrier per phase):
+//     recurrence wave : SNP block b.   s_j = S'_b[j] - (X_b'X_{b-1} delta_{b-1})[j]      cross-block Gram, precomputed
+//                                            - sum_{i<j} (X_b'X_b)[j,i] delta_i            in-block Gram
+//                       then mu, gam, m1, delta_j as src/coreLoop.cpp:69-79
+//     matrix waves    : R_K -= X_{b-1} delta_{b-1}   (update of the block finished one phase ago)
+//                       S'_{b+1} = X_{b+1}' R_K        (f64 MFMA, k = samples)
+//                       + the block's loads/stores and column sums on their otherwise idle VALU/LSU
+//   S'_{b+1} misses only the update of block b, which the recurrence wave adds as the 16x16
+//   cross-Gram correction, so the result is the same Gauss-Seidel sweep.
+//
+// LDS buffers are double-buffered by block parity; every hand-off crosses exactly one barrier.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "aq_core_sweep.h"
+
+template <int NT, int NWM>
+__global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
+  constexpr int NTT = NT * NWM;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const bool is_rec = (w == NWM);
+  const int g = lane >> 4;
+  const int col = lane & 15;
+  const int tile = blockIdx.x;
+  const bool helper = tid < 256;               // waves 0..3 are matrix waves in every instantiation (NWM >= 4)
+  const int hj = (tid >> 4) & 15, hk = tid & 15;
+  const int mr = a.dmode ? 1 : 4, mg = a.dmode ? 4 : 1;   // f64 MFMA D row = mr*reg + mg*(lane>>4)
+
+  __shared__ double Sp[2][NWM][256];   // partial S' of each matrix wave [snp][trait]
+  __shared__ double LA[2][256];        // A = log(1-Phi) - log Phi
+  __shared__ double Lm1[2][256];       // old m1 = gam*mu
+  __shared__ double LB[2][256];        // slope b of Z
+  __shared__ double LG[2][512];        // X_b'X_b as [16][32], upper 16 columns zero
+  __shared__ double LGx[2][256];       // X_b'X_{b-1}  [j][i]
+  __shared__ double Lgam[2][256], Lmu[2][256], Ldel[2][256];
+  __shared__ double Lred[4][256];      // running column sums per helper thread
+  __shared__ double Lrn[NWM * 4][16];
+
+  const size_t tbase = (size_t)tile * a.p_pad * 16;
+  double *Rg = a.R + (size_t)tile * a.n_pad * 16;
+  const int ktrait = tile * 16 + hk;
+  const bool kvalid = ktrait < a.q;
+  double sig2b_k = 1.0;
+  if (helper) {
+    sig2b_k = a.sig2b[ktrait];
+    Lred[0][tid] = Lred[1][tid] = Lred[2][tid] = Lred[3][tid] = 0.0;
+    LG[0][hj * 32 + 16 + hk] = 0.0;
+    LG[1][hj * 32 + 16 + hk] = 0.0;
+  }
+
+  if (is_rec) {
+    // =========================== recurrence wave ===========================================
+    if (a.mode == 1) {
+      for (int b = 0; b < a.nb; b++) {   // init mode: nothing to do, keep the barrier count
+        __syncthreads();
+        __syncthreads();
+      }
+    } else {
+      const int kk = tile * 16 + col;
+      const double rc_coef = a.coef[kk];
+      const double rc_cinv2s = a.c * a.inv2s[kk];
+      const double rc_cst = a.cst[kk];
+      aq_lds_barrier();   // prologue
+      for (int b = 0; b < a.nb; b++) {
+        const int par = b & 1;
+#if !(AQ_DIAG & 1)
+        // ---- SNP block b, lane = trait ---------------------------------------------------
+        double S[16], dlp[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          double s = Sp[par][0][j * 16 + col];
+#pragma unroll
+          for (int ww = 1; ww < NWM; ww++) s += Sp[par][ww][j * 16 + col];
+          S[j] = s;
+          dlp[j] = (b > 0) ? Ldel[par ^ 1][j * 16 + col] : 0.0;      // delta of block b-1
+        }
+        // cross-block correction of the first SNP; the others follow inside the loop, one row ahead
+#pragma unroll
+        for (int i = 0; i < 16; i++) S[0] -= LGx[par][i] * dlp[i];
+        double m1o = Lm1[par][col], cA = a.c * (LA[par][col] + rc_cst), dj = LG[par][0];
+#pragma unroll 1
+        for (int j = 0; j < 16; j++) {
+          const int jn = (j + 1) & 15;
+          double m1o_n = Lm1[par][jn * 16 + col], cA_n = a.c * (LA[par][jn * 16 + col] + rc_cst), d_n = LG[par][jn * 33];
+          double s = S[0] + m1o * dj;                       // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1*cp_X(j,j))   :71
+          double mu = rc_coef * s;                          // :73
+          double x = cA - (mu * mu) * rc_cinv2s;            // c*(log(1-Phi) - log Phi - mu^2/(2 sig2) + cst)   :75-77
+          // cross-block correction of the NEXT SNP (row j+1 sits in S[1]); independent of the chain
+          {
+            double cx = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) cx += LGx[par][jn * 16 + i] * dlp[i];
+            if (j < 15) S[1] -= cx;
+          }
+          double gm = aq_sigmoid_neg(x);
+          double dl = gm * mu - m1o;                        // m1 - m1_old, m1 = gam*mu   :79
+          // in-block part of :81: S shifts down by one; G[j+1+i][j] reads the zero pad past the block
+#pragma unroll
+          for (int i0 = 0; i0 < 15; i0 += 8) {
+            double gc[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) gc[i] = (i0 + i < 15) ? LG[par][j * 32 + j + 1 + i0 + i] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+              if (i0 + i < 15) S[i0 + i] = S[i0 + i + 1] - gc[i] * dl;
+          }
+          if (lane < 16) {
+            Lgam[par][j * 16 + col] = gm;
+            Lmu[par][j * 16 + col] = mu;
+            Ldel[par][j * 16 + col] = dl;
+          }
+          m1o = m1o_n; cA = cA_n; dj = d_n;
+        }
+#endif
+        aq_lds_barrier();
+      }
+    }
+    __syncthreads();   // matches the matrix waves' barrier before the final sums
+  } else {
+    // =========================== matrix waves ==============================================
+    // residual tiles: Rr[t][r] <-> sample 16*(w*NT+t) + mr*r + mg*g, trait col
+    aq_d4 Rr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Rr[t][r] = Rg[(size_t)(16 * (w * NT + t) + mr * r + mg * g) * 16 + col];
+    const double2 *XAw = a.XA + (size_t)(w * NT) * 128 + lane;
+    const double2 *XUw = a.XU + (size_t)(w * NT) * 128 + lane;
+
+    // ---- helper-thread staging (global -> registers a phase ahead -> LDS)
+    double st_A = 0, st_g = 0, st_m = 0, st_B = 0, st_G = 0, st_Gx = 0;
+    auto stage_load = [&](int b) {
+      size_t off = tbase + (size_t)(16 * b) * 16 + tid;
+      st_A = a.Aarr[off];
+      st_g = a.gam[off];
+      st_m = a.mu[off];
+      st_B = a.Barr[off];
+      st_G = a.G[(size_t)b * 256 + tid];
+      st_Gx = a.Gx[(size_t)b * 256 + tid];
+    };
+    auto stage_commit = [&](int par) {
+      LA[par][tid] = st_A;
+      Lm1[par][tid] = st_g * st_m;
+      LB[par][tid] = st_B;
+      LG[par][hj * 32 + hk] = st_G;
+      LGx[par][tid] = st_Gx;
+    };
+    // stores and column / row sums of a finished block (gam, mu, delta in LDS parity `par`)
+    auto finalize = [&](int b, int par) {
+      double gm = Lgam[par][tid], mu = Lmu[par][tid];
+      size_t off = tbase + (size_t)(16 * b) * 16 + tid;
+      a.gam[off] = gm;
+      a.mu[off] = mu;
+      const int j = 16 * b + hj;
+      double gb = 0.0;
+      if (kvalid && j < a.p) {
+        double be = gm * mu;
+        gb = gm * LB[par][tid];
+        Lred[0][tid] += gm;
+        Lred[1][tid] += (mu * mu + sig2b_k) * gm;   // update_m2_beta_, R/update_vb.R:19-31
+        Lred[2][tid] += be * be;
+        Lred[3][tid] += gb;
+      }
+      gb += __shfl_xor(gb, 8, 64);
+      gb += __shfl_xor(gb, 4, 64);
+      gb += __shfl_xor(gb, 2, 64);
+      gb += __shfl_xor(gb, 1, 64);
+      if (hk == 0) a.rowGB[(size_t)tile * a.p_pad + j] = gb;
+    };
+    // matrix work of one phase: update with block bu (delta in LDS parity pu) and/or S' of block bs -> Sp[ps]
+    auto matrix_phase = [&](bool do_u, int bu, int pu, bool do_s, int bs, int ps) {
+      double nd[4];
+      if (do_u) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) nd[s] = -Ldel[pu][(4 * s + g) * 16 + col];
+      }
+      aq_d4 acc = {0, 0, 0, 0};
+      const double2 *xu = XUw + (size_t)(do_u ? bu : 0) * NTT * 128;
+      const double2 *xa = XAw + (size_t)(do_s ? bs : 0) * NTT * 128;
+      double2 cu0 = xu[0], cu1 = xu[64], ca0 = xa[0], ca1 = xa[64];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        double2 nu0, nu1, na0, na1;
+        if (t + 1 < NT) {
+          nu0 = xu[(t + 1) * 128]; nu1 = xu[(t + 1) * 128 + 64];
+          na0 = xa[(t + 1) * 128]; na1 = xa[(t + 1) * 128 + 64];
+        }
+        aq_d4 Rt = Rr[t];
+        if (do_u) {
+          Rt = aq_mfma(cu0.x, nd[0], Rt);
+          Rt = aq_mfma(cu0.y, nd[1], Rt);
+          Rt = aq_mfma(cu1.x, nd[2], Rt);
+          Rt = aq_mfma(cu1.y, nd[3], Rt);
+          Rr[t] = Rt;
+        }
+        if (do_s) {
+          acc = aq_mfma(ca0.x, Rt[0], acc);
+          acc = aq_mfma(ca0.y, Rt[1], acc);
+          acc = aq_mfma(ca1.x, Rt[2], acc);
+          acc = aq_mfma(ca1.y, Rt[3], acc);
+        }
+        if (t + 1 < NT) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (do_s) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) Sp[ps][w][(mr * i + mg * g) * 16 + col] = acc[i];
+      }
+    };
+
+
+    if (a.mode == 1) {
+      // ---------------- init mode: R = Y - X (gam*mu), block by block; column sums of the initial state
+      for (int b = 0; b < a.nb; b++) {
+        if (helper) {
+          size_t off = tbase + (size_t)(16 * b) * 16 + tid;
+          double gm = a.gam[off], mu = a.mu[off];
+          double be = gm * mu;                                  // update_beta_vb_, R/update_vb.R:17
+          Ldel[0][tid] = be;
+          if (kvalid && (16 * b + hj) < a.p) {
+            Lred[0][tid] += gm;
+            Lred[1][tid] += (mu * mu + sig2b_k) * gm;           // initial m2_beta, R/atlasqtl_global_local_core.R:113
+            Lred[2][tid] += be * be;
+          }
+        }
+        __syncthreads();
+        matrix_phase(true, b, 0, false, 0, 0);
+        __syncthreads();
+      }
+    } else {
+      // ---------------- full sweep -----------------------------------------------------
+      // prologue: S'_0 from the untouched residual, staging of block 0
+      matrix_phase(false, 0, 0, true, 0, 0);
+      if (helper) {
+        stage_load(0);
+        stage_commit(0);
+      }
+      aq_lds_barrier();
+      for (int b = 0; b < a.nb; b++) {
+        const int par = b & 1;
+        const bool more = (b + 1 < a.nb);
+        // update with block b-1, S' of block b+1, helper duties
+        if (helper && more) stage_load(b + 1);
+#if !(AQ_DIAG & 2)
+        if (b > 0 || more) matrix_phase(b > 0, b - 1, par ^ 1, more, b + 1, par ^ 1);
+#endif
+        if (helper) {
+          if (b > 0) finalize(b - 1, par ^ 1);
+          if (more) stage_commit(par ^ 1);
+        }
+        aq_lds_barrier();
+      }
+      // epilogue: the last block's update and stores
+      const int pl = (a.nb - 1) & 1;
+#if !(AQ_DIAG & 2)
+      matrix_phase(true, a.nb - 1, pl, false, 0, 0);
+#endif
+      if (helper) finalize(a.nb - 1, pl);
+    }
+    // ---- write the residual back and ||R_k||^2 partials ----
+    double rn = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double v = Rr[t][r];
+        Rg[(size_t)(16 * (w * NT + t) + mr * r + mg * g) * 16 + col] = v;
+        rn += v * v;
+      }
+    Lrn[w * 4 + g][col] = rn;
+    __syncthreads();
+  }
+  // ---- per-trait sums ----
+  if (tid < 16) {
+    int k2 = tile * 16 + tid;
+    double r2 = 0.0;
+    for (int s = 0; s < NWM * 4; s++) r2 += Lrn[s][tid];
+    a.sums[(size_t)4 * a.q_pad + k2] = r2;
+    for (int v = 0; v < 4; v++) {
+      double acc2 = 0.0;
+      for (int jj = 0; jj < 16; jj++) acc2 += Lred[v][jj * 16 + tid];
+      a.sums[(size_t)v * a.q_pad + k2] = acc2;
+    }
+  }
+}

@@ -57,11 +57,22 @@ __global__ void aq_k_build_x_layouts(const double *__restrict__ X, double2 *__re
   }
 }
 
-// diagonal Gram blocks G[b] = X_b' X_b (16 x 16), the in-block part of cp_X (R/atlasqtl_global_local_core.R:41)
-__global__ void aq_k_gram_blocks(const double *__restrict__ X, double *__restrict__ G, int n, int p) {
+// diagonal Gram blocks G[b] = X_b' X_b and first off-diagonal blocks Gx[b] = X_b' X_{b-1} (16 x 16 each):
+// the only parts of cp_X (R/atlasqtl_global_local_core.R:41) the blocked recursion needs
+__global__ void aq_k_gram_blocks(const double *__restrict__ X, double *__restrict__ G, double *__restrict__ Gx, int n,
+                                 int p) {
   int b = blockIdx.x;
   int i = threadIdx.x >> 4, j = threadIdx.x & 15;
   int ji = 16 * b + i, jj = 16 * b + j;
+  {   // cross block with the previous SNP block: Gx[b][i][j] = x_{16b+i}' x_{16(b-1)+j}
+    int jp = 16 * (b - 1) + j;
+    double sx = 0.0;
+    if (b > 0 && ji < p && jp < p) {
+      const double *xi = X + (size_t)n * ji, *xj = X + (size_t)n * jp;
+      for (int r = 0; r < n; r++) sx += xi[r] * xj[r];
+    }
+    Gx[(size_t)b * 256 + threadIdx.x] = sx;
+  }
   double s = 0.0;
   if (ji < p && jj < p) {
     const double *xi = X + (size_t)n * ji, *xj = X + (size_t)n * jj;

@@ -14,6 +14,7 @@
 
 #include "../../include/atlasqtl_hip.h"
 #include "aq_core_sweep.h"
+#include "aq_core_sweep_la.h"
 #include "aq_gram_loop.h"
 #include "aq_special.h"
 #include "aq_vec_kernels.h"
@@ -124,13 +125,14 @@ struct aq_vb {
   bool thinned, debug;
   // device buffers
   double2 *XA = nullptr, *XU = nullptr;
-  double *G = nullptr, *R = nullptr, *gam = nullptr, *mu = nullptr;
+  double *G = nullptr, *Gx = nullptr, *R = nullptr, *gam = nullptr, *mu = nullptr;
   double *theta = nullptr, *sig2_theta = nullptr, *L = nullptr, *lam2_inv = nullptr, *Q = nullptr, *ppart = nullptr;
   double *eta_h = nullptr, *kappa_h = nullptr, *n0 = nullptr, *nobs = nullptr;
   double *zeta = nullptr, *tau = nullptr, *sig2b = nullptr, *log_tau = nullptr, *eta_vb = nullptr, *kappa_vb = nullptr;
   double *coef = nullptr, *inv2s = nullptr, *cst = nullptr, *sums = nullptr, *rowA = nullptr, *rowGB = nullptr;
   double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
   int TT = 1;
+  bool use_la = false;   // look-ahead kernel (aq_core_sweep_la.h)
   bool pre_done = false;
   double *red = nullptr, *ered = nullptr, *Hpart = nullptr;
   bool own_red = false, own_ered = false;
@@ -160,7 +162,7 @@ struct aq_vb {
 static void aq_free_all(aq_vb *s) {
   if (!s) return;
   hipSetDevice(s->device);
-  void *ptrs[] = {s->XA, s->XU, s->G, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
+  void *ptrs[] = {s->XA, s->XU, s->G, s->Gx, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
                   s->eta_h, s->kappa_h, s->n0, s->nobs, s->zeta, s->tau, s->sig2b, s->log_tau, s->eta_vb, s->kappa_vb,
                   s->coef, s->inv2s, s->cst, s->sums, s->rowA, s->rowGB, s->Aarr, s->Barr, s->colApart, s->Hpart, s->sc};
   for (void *ptr : ptrs)
@@ -197,7 +199,7 @@ static std::vector<double> aq_ladder(const double anneal[3]) {
 
 static int aq_launch_core(aq_vb *s, int mode, double c) {
   AqCoreArgs a;
-  a.XA = s->XA; a.XU = s->XU; a.G = s->G; a.R = s->R; a.gam = s->gam; a.mu = s->mu;
+  a.XA = s->XA; a.XU = s->XU; a.G = s->G; a.Gx = s->Gx; a.R = s->R; a.gam = s->gam; a.mu = s->mu;
   a.Aarr = s->Aarr; a.Barr = s->Barr; a.coef = s->coef; a.inv2s = s->inv2s; a.cst = s->cst; a.sig2b = s->sig2b;
   a.sums = s->sums; a.rowGB = s->rowGB;
   a.c = c;
@@ -208,6 +210,17 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   AQ_HIP(hipEventCreate(&e0));
   AQ_HIP(hipEventCreate(&e1));
   AQ_HIP(hipEventRecord(e0, 0));
+  if (s->use_la) {
+    dim3 gridl(s->ntile), blockl((s->NW + 1) * 64);
+#define AQ_LA(NT_, NWM_)                                                                   \
+  if (s->NT == NT_ && s->NW == NWM_) {                                                     \
+    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, NWM_>), gridl, blockl, 0, 0, a);      \
+  } else
+    AQ_LA(2, 4) AQ_LA(4, 4) AQ_LA(8, 4) AQ_LA(9, 7) AQ_LA(8, 8) {
+      return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
+    }
+#undef AQ_LA
+  } else
 #define AQ_CASE(NT_, NW_, TT_)                                                             \
   if (s->NT == NT_ && s->NW == NW_ && s->TT == TT_) {                                      \
     hipLaunchKernelGGL((aq_core_sweep_kernel<NT_, NW_, TT_>), grid, block, 0, 0, a);       \
@@ -292,12 +305,25 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     delete s;
     return aq_fail(AQ_ERR_UNSUPPORTED, "n > 2048: the register-resident residual tile does not fit (not implemented yet)");
   }
+  {
+    // default: look-ahead kernel (NW = number of matrix waves); AQ_KERNEL=1 selects the two-barrier kernel
+    const char *ek = getenv("AQ_KERNEL");
+    bool want_la = !(ek && atoi(ek) == 1);
+    if (want_la && pr->n <= 1024) {
+      s->use_la = true;
+      if (pr->n <= 128) { s->NT = 2; s->NW = 4; }
+      else if (pr->n <= 256) { s->NT = 4; s->NW = 4; }
+      else if (pr->n <= 512) { s->NT = 8; s->NW = 4; }
+      else if (pr->n <= 1008) { s->NT = 9; s->NW = 7; }
+      else { s->NT = 8; s->NW = 8; }
+    }
+  }
   s->n_pad = 16 * s->NT * s->NW;
   // trait tiles per workgroup: 1 (two workgroups per CU) unless that would need a second round of workgroups
   s->TT = 1;
   if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 3 ? 3 : 1;
   else if (s->NW == 4 && s->ntile > 512) s->TT = 3;
-  if (s->NW != 4) s->TT = 1;
+  if (s->NW != 4 || s->use_la) s->TT = 1;
   int rc = aq_probe_dmode(&s->dmode);
   if (rc != AQ_OK) { delete s; return rc; }
 
@@ -318,6 +344,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   AQ_TRYF(aq_dalloc(&s->XA, xelems));
   AQ_TRYF(aq_dalloc(&s->XU, xelems));
   AQ_TRYF(aq_dalloc(&s->G, (size_t)s->nb * 256));
+  AQ_TRYF(aq_dalloc(&s->Gx, (size_t)s->nb * 256));
   AQ_TRYF(aq_dalloc(&s->R, (size_t)s->ntile * s->n_pad * 16));
   AQ_TRYF(aq_dalloc(&s->gam, (size_t)s->ntile * s->p_pad * 16));
   AQ_TRYF(aq_dalloc(&s->mu, (size_t)s->ntile * s->p_pad * 16));
@@ -353,7 +380,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     AQ_HIPF(hipMemcpy(Xd, pr->X, np * sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(aq_k_build_x_layouts, dim3((unsigned)((xelems + 255) / 256)), dim3(256), 0, 0, Xd, s->XA, s->XU,
                        s->n, s->p, s->nb, NTT, s->dmode);
-    hipLaunchKernelGGL(aq_k_gram_blocks, dim3(s->nb), dim3(256), 0, 0, Xd, s->G, s->n, s->p);
+    hipLaunchKernelGGL(aq_k_gram_blocks, dim3(s->nb), dim3(256), 0, 0, Xd, s->G, s->Gx, s->n, s->p);
     AQ_HIPF(hipDeviceSynchronize());
     AQ_HIPF(hipFree(Xd));
   }
