@@ -59,6 +59,8 @@ struct AqCoreArgs {
   int p_pad, q_pad, n_pad, nb, ntile;
   int dmode;             // f64 MFMA D layout: 0 -> row = (l>>4) + 4*reg, 1 -> row = 4*(l>>4) + reg
   int mode;              // 0 = full sweep, 1 = init: R -= X (gam*mu) only
+  int wt_base[16];       // look-ahead kernel: first residual tile of each matrix wave ...
+  int wt_cnt[16];        // ... and how many it owns (uneven: the wave sharing a SIMD with the recurrence wave gets fewer)
 };
 
 __device__ __forceinline__ aq_d4 aq_mfma(double a, double b, aq_d4 c) {

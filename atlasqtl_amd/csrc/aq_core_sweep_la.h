@@ -24,7 +24,6 @@
 
 template <int NT, int NWM>
 __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
-  constexpr int NTT = NT * NWM;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
@@ -128,14 +127,18 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
     __syncthreads();   // matches the matrix waves' barrier before the final sums
   } else {
     // =========================== matrix waves ==============================================
-    // residual tiles: Rr[t][r] <-> sample 16*(w*NT+t) + mr*r + mg*g, trait col
+    // residual tiles: Rr[t][r] <-> sample 16*(my_t0+t) + mr*r + mg*g, trait col
+    // (NT = most tiles any wave owns; this wave owns my_nt of them starting at tile my_t0)
+    const int my_t0 = a.wt_base[w], my_nt = a.wt_cnt[w];
+    const int NTT = a.n_pad / 16;
     aq_d4 Rr[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) Rr[t][r] = Rg[(size_t)(16 * (w * NT + t) + mr * r + mg * g) * 16 + col];
-    const double2 *XAw = a.XA + (size_t)(w * NT) * 128 + lane;
-    const double2 *XUw = a.XU + (size_t)(w * NT) * 128 + lane;
+      for (int r = 0; r < 4; r++)
+        Rr[t][r] = (t < my_nt) ? Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col] : 0.0;
+    const double2 *XAw = a.XA + (size_t)my_t0 * 128 + lane;
+    const double2 *XUw = a.XU + (size_t)my_t0 * 128 + lane;
 
     // ---- helper-thread staging (global -> registers a phase ahead -> LDS)
     double st_A = 0, st_g = 0, st_m = 0, st_B = 0, st_G = 0, st_Gx = 0;
@@ -187,11 +190,13 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
       aq_d4 acc = {0, 0, 0, 0};
       const double2 *xu = XUw + (size_t)(do_u ? bu : 0) * NTT * 128;
       const double2 *xa = XAw + (size_t)(do_s ? bs : 0) * NTT * 128;
-      double2 cu0 = xu[0], cu1 = xu[64], ca0 = xa[0], ca1 = xa[64];
+      double2 cu0 = {0, 0}, cu1 = {0, 0}, ca0 = {0, 0}, ca1 = {0, 0};
+      if (my_nt > 0) { cu0 = xu[0]; cu1 = xu[64]; ca0 = xa[0]; ca1 = xa[64]; }
 #pragma unroll
       for (int t = 0; t < NT; t++) {
+        if (t >= my_nt) break;
         double2 nu0, nu1, na0, na1;
-        if (t + 1 < NT) {
+        if (t + 1 < NT && t + 1 < my_nt) {
           nu0 = xu[(t + 1) * 128]; nu1 = xu[(t + 1) * 128 + 64];
           na0 = xa[(t + 1) * 128]; na1 = xa[(t + 1) * 128 + 64];
         }
@@ -209,7 +214,7 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
           acc = aq_mfma(ca1.x, Rt[2], acc);
           acc = aq_mfma(ca1.y, Rt[3], acc);
         }
-        if (t + 1 < NT) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
+        if (t + 1 < NT && t + 1 < my_nt) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (do_s) {
@@ -273,9 +278,11 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
     for (int t = 0; t < NT; t++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        double v = Rr[t][r];
-        Rg[(size_t)(16 * (w * NT + t) + mr * r + mg * g) * 16 + col] = v;
-        rn += v * v;
+        if (t < my_nt) {
+          double v = Rr[t][r];
+          Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col] = v;
+          rn += v * v;
+        }
       }
     Lrn[w * 4 + g][col] = rn;
     __syncthreads();

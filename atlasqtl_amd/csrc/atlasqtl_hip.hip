@@ -133,6 +133,7 @@ struct aq_vb {
   double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
   int TT = 1;
   bool use_la = false;   // look-ahead kernel (aq_core_sweep_la.h)
+  int wt_base[16] = {0}, wt_cnt[16] = {0};
   bool pre_done = false;
   double *red = nullptr, *ered = nullptr, *Hpart = nullptr;
   bool own_red = false, own_ered = false;
@@ -216,7 +217,8 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   if (s->NT == NT_ && s->NW == NWM_) {                                                     \
     hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, NWM_>), gridl, blockl, 0, 0, a);      \
   } else
-    AQ_LA(2, 4) AQ_LA(4, 4) AQ_LA(8, 4) AQ_LA(9, 7) AQ_LA(8, 8) {
+    for (int i = 0; i < 16; i++) { a.wt_base[i] = s->wt_base[i]; a.wt_cnt[i] = s->wt_cnt[i]; }
+    AQ_LA(2, 4) AQ_LA(4, 4) AQ_LA(8, 4) AQ_LA(2, 7) AQ_LA(4, 7) AQ_LA(8, 7) AQ_LA(11, 7) {
       return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
     }
 #undef AQ_LA
@@ -310,15 +312,34 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     const char *ek = getenv("AQ_KERNEL");
     bool want_la = !(ek && atoi(ek) == 1);
     if (want_la && pr->n <= 1024) {
+      // NW matrix waves + 1 recurrence wave (wave NW).  Waves i and i+4 share a SIMD, and the recurrence
+      // wave's fp64 chain is serialised behind f64 MFMAs issued on its SIMD, so its partner (wave NW-4)
+      // gets `pt` residual tiles only; the other waves split the rest evenly.
       s->use_la = true;
-      if (pr->n <= 128) { s->NT = 2; s->NW = 4; }
-      else if (pr->n <= 256) { s->NT = 4; s->NW = 4; }
-      else if (pr->n <= 512) { s->NT = 8; s->NW = 4; }
-      else if (pr->n <= 1008) { s->NT = 9; s->NW = 7; }
-      else { s->NT = 8; s->NW = 8; }
+      const int ntiles = (pr->n + 15) / 16;
+      s->NW = ntiles <= 32 ? 4 : 7;
+      int pt = 0;
+      if (const char *e = getenv("AQ_PARTNER_TILES")) pt = atoi(e);
+      const int partner = s->NW - 4;
+      const int others = s->NW - 1;
+      if (pt > ntiles) pt = ntiles;
+      int rest = ntiles - pt, t0 = 0, ntmax = 0;
+      for (int w2 = 0; w2 < s->NW; w2++) {
+        int cnt;
+        if (w2 == partner) cnt = pt;
+        else {
+          int idx = w2 < partner ? w2 : w2 - 1;
+          cnt = rest / others + (idx < rest % others ? 1 : 0);
+        }
+        s->wt_base[w2] = t0; s->wt_cnt[w2] = cnt; t0 += cnt;
+        if (cnt > ntmax) ntmax = cnt;
+      }
+      s->NT = ntmax <= 2 ? 2 : ntmax <= 4 ? 4 : ntmax <= 8 ? 8 : 11;
+      if (ntmax > 11) { s->use_la = false; s->NT = 16; s->NW = 4; }   // falls back to the two-barrier kernel
+      else s->n_pad = 16 * ntiles;
     }
   }
-  s->n_pad = 16 * s->NT * s->NW;
+  if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
   // trait tiles per workgroup: 1 (two workgroups per CU) unless that would need a second round of workgroups
   s->TT = 1;
   if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 3 ? 3 : 1;
@@ -339,7 +360,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
 #define AQ_TRYF(x) do { int rc2_ = (x); if (rc2_ != AQ_OK) return fail(rc2_); } while (0)
 #define AQ_HIPF(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { aq_fail(AQ_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(AQ_ERR_DEVICE); } } while (0)
 
-  const int NTT = s->NT * s->NW;
+  const int NTT = s->n_pad / 16;
   size_t xelems = (size_t)s->nb * NTT * 128;
   AQ_TRYF(aq_dalloc(&s->XA, xelems));
   AQ_TRYF(aq_dalloc(&s->XU, xelems));
