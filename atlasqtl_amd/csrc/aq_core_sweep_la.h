@@ -5,8 +5,10 @@
 // ~23 dependent fp64 operations per SNP that cannot be shortened -- runs CONCURRENTLY with the
 // matrix work instead of between two barriers:
 //
-//   workgroup = NWM "matrix" waves (each owns NT 16-sample tiles of the residual R_K in VGPRs)
-//             + 1 "recurrence" wave (lane = trait, owns no residual)
+//   workgroup = 7 waves: 6 "matrix" waves (each owns exactly NT 16-sample tiles of the residual R_K in VGPRs)
+//             + 1 "recurrence" wave (lane = trait, owns no residual).  The recurrence wave is wave 3: waves i and
+//             i+4 of a workgroup share a SIMD, so wave 3 of 7 has a SIMD to itself -- its chain of dependent fp64
+//             operations would otherwise wait behind every f64 MFMA issued on that SIMD (measured: 2.6x slower)
 //   phase b (one barrier per phase):
 //     recurrence wave : SNP block b.   s_j = S'_b[j] - (X_b'X_{b-1} delta_{b-1})[j]      cross-block Gram, precomputed
 //                                            - sum_{i<j} (X_b'X_b)[j,i] delta_i            in-block Gram
@@ -22,17 +24,20 @@
 #include <hip/hip_runtime.h>
 #include "aq_core_sweep.h"
 
-template <int NT, int NWM>
-__global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
+template <int NT>
+__global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
+  constexpr int NWM = 6;                        // matrix waves: 0,1,2,4,5,6
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
-  const bool is_rec = (w == NWM);
+  const bool is_rec = (w == 3);
+  const int mw = w < 3 ? w : w - 1;             // matrix-wave index 0..5
   const int g = lane >> 4;
   const int col = lane & 15;
   const int tile = blockIdx.x;
-  const bool helper = tid < 256;               // waves 0..3 are matrix waves in every instantiation (NWM >= 4)
-  const int hj = (tid >> 4) & 15, hk = tid & 15;
+  const bool helper = (w < 3) || (w == 4);      // 256 helper threads on matrix waves 0,1,2,4
+  const int hid = w < 3 ? tid : tid - 64;       // 0..255
+  const int hj = (hid >> 4) & 15, hk = hid & 15;
   const int mr = a.dmode ? 1 : 4, mg = a.dmode ? 4 : 1;   // f64 MFMA D row = mr*reg + mg*(lane>>4)
 
   __shared__ double Sp[2][NWM][256];   // partial S' of each matrix wave [snp][trait]
@@ -52,7 +57,7 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
   double sig2b_k = 1.0;
   if (helper) {
     sig2b_k = a.sig2b[ktrait];
-    Lred[0][tid] = Lred[1][tid] = Lred[2][tid] = Lred[3][tid] = 0.0;
+    Lred[0][hid] = Lred[1][hid] = Lred[2][hid] = Lred[3][hid] = 0.0;
     LG[0][hj * 32 + 16 + hk] = 0.0;
     LG[1][hj * 32 + 16 + hk] = 0.0;
   }
@@ -128,51 +133,49 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
   } else {
     // =========================== matrix waves ==============================================
     // residual tiles: Rr[t][r] <-> sample 16*(my_t0+t) + mr*r + mg*g, trait col
-    // (NT = most tiles any wave owns; this wave owns my_nt of them starting at tile my_t0)
-    const int my_t0 = a.wt_base[w], my_nt = a.wt_cnt[w];
-    const int NTT = a.n_pad / 16;
+    constexpr int NTT = NT * NWM;
+    const int my_t0 = mw * NT;
     aq_d4 Rr[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        Rr[t][r] = (t < my_nt) ? Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col] : 0.0;
+      for (int r = 0; r < 4; r++) Rr[t][r] = Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col];
     const double2 *XAw = a.XA + (size_t)my_t0 * 128 + lane;
     const double2 *XUw = a.XU + (size_t)my_t0 * 128 + lane;
 
     // ---- helper-thread staging (global -> registers a phase ahead -> LDS)
     double st_A = 0, st_g = 0, st_m = 0, st_B = 0, st_G = 0, st_Gx = 0;
     auto stage_load = [&](int b) {
-      size_t off = tbase + (size_t)(16 * b) * 16 + tid;
+      size_t off = tbase + (size_t)(16 * b) * 16 + hid;
       st_A = a.Aarr[off];
       st_g = a.gam[off];
       st_m = a.mu[off];
       st_B = a.Barr[off];
-      st_G = a.G[(size_t)b * 256 + tid];
-      st_Gx = a.Gx[(size_t)b * 256 + tid];
+      st_G = a.G[(size_t)b * 256 + hid];
+      st_Gx = a.Gx[(size_t)b * 256 + hid];
     };
     auto stage_commit = [&](int par) {
-      LA[par][tid] = st_A;
-      Lm1[par][tid] = st_g * st_m;
-      LB[par][tid] = st_B;
+      LA[par][hid] = st_A;
+      Lm1[par][hid] = st_g * st_m;
+      LB[par][hid] = st_B;
       LG[par][hj * 32 + hk] = st_G;
-      LGx[par][tid] = st_Gx;
+      LGx[par][hid] = st_Gx;
     };
     // stores and column / row sums of a finished block (gam, mu, delta in LDS parity `par`)
     auto finalize = [&](int b, int par) {
-      double gm = Lgam[par][tid], mu = Lmu[par][tid];
-      size_t off = tbase + (size_t)(16 * b) * 16 + tid;
+      double gm = Lgam[par][hid], mu = Lmu[par][hid];
+      size_t off = tbase + (size_t)(16 * b) * 16 + hid;
       a.gam[off] = gm;
       a.mu[off] = mu;
       const int j = 16 * b + hj;
       double gb = 0.0;
       if (kvalid && j < a.p) {
         double be = gm * mu;
-        gb = gm * LB[par][tid];
-        Lred[0][tid] += gm;
-        Lred[1][tid] += (mu * mu + sig2b_k) * gm;   // update_m2_beta_, R/update_vb.R:19-31
-        Lred[2][tid] += be * be;
-        Lred[3][tid] += gb;
+        gb = gm * LB[par][hid];
+        Lred[0][hid] += gm;
+        Lred[1][hid] += (mu * mu + sig2b_k) * gm;   // update_m2_beta_, R/update_vb.R:19-31
+        Lred[2][hid] += be * be;
+        Lred[3][hid] += gb;
       }
       gb += __shfl_xor(gb, 8, 64);
       gb += __shfl_xor(gb, 4, 64);
@@ -190,13 +193,11 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
       aq_d4 acc = {0, 0, 0, 0};
       const double2 *xu = XUw + (size_t)(do_u ? bu : 0) * NTT * 128;
       const double2 *xa = XAw + (size_t)(do_s ? bs : 0) * NTT * 128;
-      double2 cu0 = {0, 0}, cu1 = {0, 0}, ca0 = {0, 0}, ca1 = {0, 0};
-      if (my_nt > 0) { cu0 = xu[0]; cu1 = xu[64]; ca0 = xa[0]; ca1 = xa[64]; }
+      double2 cu0 = xu[0], cu1 = xu[64], ca0 = xa[0], ca1 = xa[64];
 #pragma unroll
       for (int t = 0; t < NT; t++) {
-        if (t >= my_nt) break;
         double2 nu0, nu1, na0, na1;
-        if (t + 1 < NT && t + 1 < my_nt) {
+        if (t + 1 < NT) {
           nu0 = xu[(t + 1) * 128]; nu1 = xu[(t + 1) * 128 + 64];
           na0 = xa[(t + 1) * 128]; na1 = xa[(t + 1) * 128 + 64];
         }
@@ -214,12 +215,12 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
           acc = aq_mfma(ca1.x, Rt[2], acc);
           acc = aq_mfma(ca1.y, Rt[3], acc);
         }
-        if (t + 1 < NT && t + 1 < my_nt) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
+        if (t + 1 < NT) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (do_s) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) Sp[ps][w][(mr * i + mg * g) * 16 + col] = acc[i];
+        for (int i = 0; i < 4; i++) Sp[ps][mw][(mr * i + mg * g) * 16 + col] = acc[i];
       }
     };
 
@@ -228,14 +229,14 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
       // ---------------- init mode: R = Y - X (gam*mu), block by block; column sums of the initial state
       for (int b = 0; b < a.nb; b++) {
         if (helper) {
-          size_t off = tbase + (size_t)(16 * b) * 16 + tid;
+          size_t off = tbase + (size_t)(16 * b) * 16 + hid;
           double gm = a.gam[off], mu = a.mu[off];
           double be = gm * mu;                                  // update_beta_vb_, R/update_vb.R:17
-          Ldel[0][tid] = be;
+          Ldel[0][hid] = be;
           if (kvalid && (16 * b + hj) < a.p) {
-            Lred[0][tid] += gm;
-            Lred[1][tid] += (mu * mu + sig2b_k) * gm;           // initial m2_beta, R/atlasqtl_global_local_core.R:113
-            Lred[2][tid] += be * be;
+            Lred[0][hid] += gm;
+            Lred[1][hid] += (mu * mu + sig2b_k) * gm;           // initial m2_beta, R/atlasqtl_global_local_core.R:113
+            Lred[2][hid] += be * be;
           }
         }
         __syncthreads();
@@ -278,13 +279,11 @@ __global__ __launch_bounds__((NWM + 1) * 64, (NWM + 1 + 3) / 4) void aq_core_swe
     for (int t = 0; t < NT; t++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        if (t < my_nt) {
-          double v = Rr[t][r];
-          Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col] = v;
-          rn += v * v;
-        }
+        double v = Rr[t][r];
+        Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col] = v;
+        rn += v * v;
       }
-    Lrn[w * 4 + g][col] = rn;
+    Lrn[mw * 4 + g][col] = rn;
     __syncthreads();
   }
   // ---- per-trait sums ----

@@ -212,13 +212,12 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   AQ_HIP(hipEventCreate(&e1));
   AQ_HIP(hipEventRecord(e0, 0));
   if (s->use_la) {
-    dim3 gridl(s->ntile), blockl((s->NW + 1) * 64);
-#define AQ_LA(NT_, NWM_)                                                                   \
-  if (s->NT == NT_ && s->NW == NWM_) {                                                     \
-    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, NWM_>), gridl, blockl, 0, 0, a);      \
+    dim3 gridl(s->ntile), blockl(7 * 64);
+#define AQ_LA(NT_)                                                                   \
+  if (s->NT == NT_) {                                                                \
+    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_>), gridl, blockl, 0, 0, a);      \
   } else
-    for (int i = 0; i < 16; i++) { a.wt_base[i] = s->wt_base[i]; a.wt_cnt[i] = s->wt_cnt[i]; }
-    AQ_LA(2, 4) AQ_LA(4, 4) AQ_LA(8, 4) AQ_LA(2, 7) AQ_LA(4, 7) AQ_LA(8, 7) AQ_LA(11, 7) {
+    AQ_LA(1) AQ_LA(2) AQ_LA(3) AQ_LA(4) AQ_LA(5) AQ_LA(6) AQ_LA(7) AQ_LA(8) AQ_LA(9) AQ_LA(10) AQ_LA(11) {
       return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
     }
 #undef AQ_LA
@@ -312,31 +311,13 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     const char *ek = getenv("AQ_KERNEL");
     bool want_la = !(ek && atoi(ek) == 1);
     if (want_la && pr->n <= 1024) {
-      // NW matrix waves + 1 recurrence wave (wave NW).  Waves i and i+4 share a SIMD, and the recurrence
-      // wave's fp64 chain is serialised behind f64 MFMAs issued on its SIMD, so its partner (wave NW-4)
-      // gets `pt` residual tiles only; the other waves split the rest evenly.
+      // 6 matrix waves x NT residual tiles each (n padded to 96 NT samples) + the recurrence wave
       s->use_la = true;
       const int ntiles = (pr->n + 15) / 16;
-      s->NW = ntiles <= 32 ? 4 : 7;
-      int pt = 0;
-      if (const char *e = getenv("AQ_PARTNER_TILES")) pt = atoi(e);
-      const int partner = s->NW - 4;
-      const int others = s->NW - 1;
-      if (pt > ntiles) pt = ntiles;
-      int rest = ntiles - pt, t0 = 0, ntmax = 0;
-      for (int w2 = 0; w2 < s->NW; w2++) {
-        int cnt;
-        if (w2 == partner) cnt = pt;
-        else {
-          int idx = w2 < partner ? w2 : w2 - 1;
-          cnt = rest / others + (idx < rest % others ? 1 : 0);
-        }
-        s->wt_base[w2] = t0; s->wt_cnt[w2] = cnt; t0 += cnt;
-        if (cnt > ntmax) ntmax = cnt;
-      }
-      s->NT = ntmax <= 2 ? 2 : ntmax <= 4 ? 4 : ntmax <= 8 ? 8 : 11;
-      if (ntmax > 11) { s->use_la = false; s->NT = 16; s->NW = 4; }   // falls back to the two-barrier kernel
-      else s->n_pad = 16 * ntiles;
+      s->NW = 6;
+      s->NT = (ntiles + 5) / 6;
+      if (s->NT > 11) { s->use_la = false; s->NT = 16; s->NW = 4; }   // falls back to the two-barrier kernel
+      else s->n_pad = 16 * 6 * s->NT;
     }
   }
   if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
