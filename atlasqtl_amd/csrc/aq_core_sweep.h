@@ -59,6 +59,9 @@ struct AqCoreArgs {
   int p_pad, q_pad, n_pad, nb, ntile;
   int dmode;             // f64 MFMA D layout: 0 -> row = (l>>4) + 4*reg, 1 -> row = 4*(l>>4) + reg
   int mode;              // 0 = full sweep, 1 = init: R -= X (gam*mu) only
+  int tile_first;        // look-ahead kernel: first trait tile of this launch
+  int b_begin, b_end;    // look-ahead kernel: SNP blocks [b_begin, b_end) handled by this launch (one segment)
+  int sums_slot;         // per-segment slot of the column sums: sums[slot][5][q_pad]
   int wt_base[16];       // look-ahead kernel: first residual tile of each matrix wave ...
   int wt_cnt[16];        // ... and how many it owns (uneven: the wave sharing a SIMD with the recurrence wave gets fewer)
 };

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   const int mw = w < 3 ? w : w - 1;             // matrix-wave index 0..5
   const int g = lane >> 4;
   const int col = lane & 15;
-  const int tile = blockIdx.x;
+  const int tile = a.tile_first + blockIdx.x;
   const bool helper = (w < 3) || (w == 4);      // 256 helper threads on matrix waves 0,1,2,4
   const int hid = w < 3 ? tid : tid - 64;       // 0..255
   const int hj = (hid >> 4) & 15, hk = hid & 15;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   if (is_rec) {
     // =========================== recurrence wave ===========================================
     if (a.mode == 1) {
-      for (int b = 0; b < a.nb; b++) {   // init mode: nothing to do, keep the barrier count
+      for (int b = a.b_begin; b < a.b_end; b++) {   // init mode: nothing to do, keep the barrier count
         __syncthreads();
         __syncthreads();
       }
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const double rc_cinv2s = a.c * a.inv2s[kk];
       const double rc_cst = a.cst[kk];
       aq_lds_barrier();   // prologue
-      for (int b = 0; b < a.nb; b++) {
+      for (int b = a.b_begin; b < a.b_end; b++) {
         const int par = b & 1;
 #if !(AQ_DIAG & 1)
         // ---- SNP block b, lane = trait ---------------------------------------------------
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #pragma unroll
           for (int ww = 1; ww < NWM; ww++) s += Sp[par][ww][j * 16 + col];
           S[j] = s;
-          dlp[j] = (b > 0) ? Ldel[par ^ 1][j * 16 + col] : 0.0;      // delta of block b-1
+          dlp[j] = (b > a.b_begin) ? Ldel[par ^ 1][j * 16 + col] : 0.0;   // delta of block b-1 (a segment starts from a complete residual)
         }
         // cross-block correction of the first SNP; the others follow inside the loop, one row ahead
 #pragma unroll
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 
     if (a.mode == 1) {
       // ---------------- init mode: R = Y - X (gam*mu), block by block; column sums of the initial state
-      for (int b = 0; b < a.nb; b++) {
+      for (int b = a.b_begin; b < a.b_end; b++) {
         if (helper) {
           size_t off = tbase + (size_t)(16 * b) * 16 + hid;
           double gm = a.gam[off], mu = a.mu[off];
@@ -246,32 +246,32 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     } else {
       // ---------------- full sweep -----------------------------------------------------
       // prologue: S'_0 from the untouched residual, staging of block 0
-      matrix_phase(false, 0, 0, true, 0, 0);
+      matrix_phase(false, 0, 0, true, a.b_begin, a.b_begin & 1);
       if (helper) {
-        stage_load(0);
-        stage_commit(0);
+        stage_load(a.b_begin);
+        stage_commit(a.b_begin & 1);
       }
       aq_lds_barrier();
-      for (int b = 0; b < a.nb; b++) {
+      for (int b = a.b_begin; b < a.b_end; b++) {
         const int par = b & 1;
-        const bool more = (b + 1 < a.nb);
+        const bool more = (b + 1 < a.b_end);
         // update with block b-1, S' of block b+1, helper duties
         if (helper && more) stage_load(b + 1);
 #if !(AQ_DIAG & 2)
-        if (b > 0 || more) matrix_phase(b > 0, b - 1, par ^ 1, more, b + 1, par ^ 1);
+        if (b > a.b_begin || more) matrix_phase(b > a.b_begin, b - 1, par ^ 1, more, b + 1, par ^ 1);
 #endif
         if (helper) {
-          if (b > 0) finalize(b - 1, par ^ 1);
+          if (b > a.b_begin) finalize(b - 1, par ^ 1);
           if (more) stage_commit(par ^ 1);
         }
         aq_lds_barrier();
       }
       // epilogue: the last block's update and stores
-      const int pl = (a.nb - 1) & 1;
+      const int pl = (a.b_end - 1) & 1;
 #if !(AQ_DIAG & 2)
-      matrix_phase(true, a.nb - 1, pl, false, 0, 0);
+      matrix_phase(true, a.b_end - 1, pl, false, 0, 0);
 #endif
-      if (helper) finalize(a.nb - 1, pl);
+      if (helper) finalize(a.b_end - 1, pl);
     }
     // ---- write the residual back and ||R_k||^2 partials ----
     double rn = 0.0;
@@ -291,11 +291,12 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     int k2 = tile * 16 + tid;
     double r2 = 0.0;
     for (int s = 0; s < NWM * 4; s++) r2 += Lrn[s][tid];
-    a.sums[(size_t)4 * a.q_pad + k2] = r2;
+    double *sm = a.sums + (size_t)a.sums_slot * 5 * a.q_pad;
+    sm[(size_t)4 * a.q_pad + k2] = r2;
     for (int v = 0; v < 4; v++) {
       double acc2 = 0.0;
       for (int jj = 0; jj < 16; jj++) acc2 += Lred[v][jj * 16 + tid];
-      a.sums[(size_t)v * a.q_pad + k2] = acc2;
+      sm[(size_t)v * a.q_pad + k2] = acc2;
     }
   }
 }

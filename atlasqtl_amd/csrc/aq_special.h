@@ -35,6 +35,22 @@ AQ_HD double aq_log_ndtr(double x) {
   return -0.5 * x * x - log(-x) - AQ_LOG_SQRT_2PI + log(ser);
 }
 
+// log Phi(x) and log(1 - Phi(x)) = log Phi(-x) from ONE erfc: with e = erfc(|x|/sqrt2)/2 (the tail on the far
+// side of x), the near-side value is log1p(-e) and the far-side one log(e).  Same formulas as aq_log_ndtr.
+AQ_HD void aq_log_ndtr_pair(double x, double *lP, double *l1) {
+  double ax = fabs(x);
+  double near_, far_;
+  if (ax < 37.0) {
+    double e = 0.5 * erfc(ax * AQ_INV_SQRT2);
+    near_ = log1p(-e);
+    far_ = log(e);
+  } else {
+    near_ = aq_log_ndtr(ax);
+    far_ = aq_log_ndtr(-ax);
+  }
+  if (x > 0.0) { *lP = near_; *l1 = far_; } else { *lP = far_; *l1 = near_; }
+}
+
 // exp(-log(1+exp(x))) evaluated as the reference's logOnePlusExp does its case
 // split (m = max(x,0)): x < 0 -> 1/(1+e^x); x >= 0 -> e^-x/(1+e^-x).
 AQ_HD double aq_sigmoid_neg(double x) {

@@ -170,14 +170,14 @@ __global__ __launch_bounds__(256) void aq_k_prepass(AqPrepass v) {
     double A = 0.0, B = 0.0, aa = 0.0;
     if (j < v.p && kvalid) {
       double u = v.theta[j] + zk;
-      double lP = aq_log_ndtr(u), l1 = aq_log_ndtr(-u);
+      double lP, l1;
+      aq_log_ndtr_pair(u, &lP, &l1);
       A = l1 - lP;
       double U = u, lPc = lP, l1c = l1, sc = 1.0;
       if (!v.c_is_one) {
         sc = v.sqrt_c;
         U = sc * u;
-        lPc = aq_log_ndtr(U);
-        l1c = aq_log_ndtr(-U);
+        aq_log_ndtr_pair(U, &lPc, &l1c);
       }
       double base = -0.5 * U * U - AQ_LOG_SQRT_2PI;
       double imr1 = exp(base - lPc);
@@ -279,6 +279,26 @@ __global__ void aq_k_reduce_rows(const double *__restrict__ rowA, const double *
   double s = 0.0;
   for (int t = 0; t < ntile; t++) s += rowA[(size_t)t * p_pad + j] + rowGB[(size_t)t * p_pad + j];
   red[j] = s;
+}
+
+// sums[0] <- column sums added over the SNP-segment slots (fixed order).  Groups of trait tiles may leave
+// their last slot empty (zeroed); ||R||^2 is taken from the last slot that group actually used.
+__global__ void aq_k_combine_segment_sums(double *sums, int q_pad, int nslot, int ntile, int ngroup) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= q_pad) return;
+  size_t Q = q_pad;
+  for (int v = 0; v < 4; v++) {
+    double acc = sums[v * Q + k];
+    for (int s = 1; s < nslot; s++) acc += sums[(size_t)s * 5 * Q + v * Q + k];
+    sums[v * Q + k] = acc;
+  }
+  // group of this trait's tile: group 0 ends in slot nslot-2 (its boundaries are unshifted), the others in nslot-1
+  int tile = k / 16, gi = 0;
+  for (int g2 = 0; g2 < ngroup; g2++)
+    if (tile >= (int)((long long)ntile * g2 / ngroup)) gi = g2;
+  int last = (gi == 0) ? nslot - 2 : nslot - 1;
+  if (last < 0) last = 0;
+  sums[4 * Q + k] = sums[(size_t)last * 5 * Q + 4 * Q + k];
 }
 
 __device__ __forceinline__ double aq_block_sum_1024(double v, double *sh) {

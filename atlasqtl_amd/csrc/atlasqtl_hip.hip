@@ -133,7 +133,10 @@ struct aq_vb {
   double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
   int TT = 1;
   bool use_la = false;   // look-ahead kernel (aq_core_sweep_la.h)
-  int wt_base[16] = {0}, wt_cnt[16] = {0};
+  int ncu = 256;
+  int nseg = 1, ngroup = 1; // SNP segments x trait-tile groups (streams) of the full-sweep launches
+  hipStream_t gstream[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   bool pre_done = false;
   double *red = nullptr, *ered = nullptr, *Hpart = nullptr;
   bool own_red = false, own_ered = false;
@@ -174,6 +177,11 @@ static void aq_free_all(aq_vb *s) {
     hipEventDestroy(e.first);
     hipEventDestroy(e.second);
   }
+  for (int gi = 0; gi < 4; gi++) {
+    if (s->gstream[gi]) hipStreamDestroy(s->gstream[gi]);
+    if (s->ev_join[gi]) hipEventDestroy(s->ev_join[gi]);
+  }
+  if (s->ev_fork) hipEventDestroy(s->ev_fork);
   delete s;
 }
 
@@ -212,15 +220,53 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   AQ_HIP(hipEventCreate(&e1));
   AQ_HIP(hipEventRecord(e0, 0));
   if (s->use_la) {
-    dim3 gridl(s->ntile), blockl(7 * 64);
+    dim3 blockl(7 * 64);
+    a.tile_first = 0; a.b_begin = 0; a.b_end = s->nb; a.sums_slot = 0;
+    auto launch = [&](int t_lo, int t_hi, int b0, int b1, int slot, hipStream_t st) -> int {
+      if (t_hi <= t_lo || b1 <= b0) return AQ_OK;
+      AqCoreArgs b = a;
+      b.tile_first = t_lo; b.b_begin = b0; b.b_end = b1; b.sums_slot = slot;
+      dim3 gridl(t_hi - t_lo);
 #define AQ_LA(NT_)                                                                   \
   if (s->NT == NT_) {                                                                \
-    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_>), gridl, blockl, 0, 0, a);      \
+    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_>), gridl, blockl, 0, st, b);     \
   } else
-    AQ_LA(1) AQ_LA(2) AQ_LA(3) AQ_LA(4) AQ_LA(5) AQ_LA(6) AQ_LA(7) AQ_LA(8) AQ_LA(9) AQ_LA(10) AQ_LA(11) {
-      return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
-    }
+      AQ_LA(1) AQ_LA(2) AQ_LA(3) AQ_LA(4) AQ_LA(5) AQ_LA(6) AQ_LA(7) AQ_LA(8) AQ_LA(9) AQ_LA(10) AQ_LA(11) {
+        return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
+      }
 #undef AQ_LA
+      return AQ_OK;
+    };
+    if (mode == 1 || (s->nseg <= 1 && s->ngroup <= 1)) {
+      AQ_TRY(launch(0, s->ntile, 0, s->nb, 0, 0));
+    } else {
+      const int G = s->ngroup, S = s->nseg;
+      if (G > 1) AQ_HIP(hipEventRecord(s->ev_fork, 0));
+      for (int gi = 0; gi < G; gi++) {
+        hipStream_t st = G > 1 ? s->gstream[gi] : (hipStream_t)0;
+        if (G > 1) AQ_HIP(hipStreamWaitEvent(st, s->ev_fork, 0));
+        const int t_lo = (int)((long long)s->ntile * gi / G), t_hi = (int)((long long)s->ntile * (gi + 1) / G);
+        // group gi's boundaries are shifted by gi/G of a segment: S + 1 launches, the first and last shorter
+        int prev = 0;
+        for (int sg = 0; sg <= S; sg++) {
+          long long num = (long long)s->nb * ((long long)(sg + 1) * G - gi);
+          int b1 = sg == S ? s->nb : (int)(num / ((long long)S * G));
+          if (b1 > s->nb) b1 = s->nb;
+          if (b1 > prev) AQ_TRY(launch(t_lo, t_hi, prev, b1, sg, st));
+          else {
+            for (int v = 0; v < 5; v++)   // empty slot, this group's traits only (other groups write theirs concurrently)
+              AQ_HIP(hipMemsetAsync(s->sums + ((size_t)sg * 5 + v) * s->q_pad + (size_t)t_lo * 16, 0,
+                                    (size_t)(t_hi - t_lo) * 16 * sizeof(double), st));
+          }
+          prev = b1;
+        }
+        if (G > 1) {
+          AQ_HIP(hipEventRecord(s->ev_join[gi], st));
+          AQ_HIP(hipStreamWaitEvent(0, s->ev_join[gi], 0));
+        }
+      }
+      hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, S + 1, s->ntile, G);
+    }
   } else
 #define AQ_CASE(NT_, NW_, TT_)                                                             \
   if (s->NT == NT_ && s->NW == NW_ && s->TT == TT_) {                                      \
@@ -318,6 +364,16 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       s->NT = (ntiles + 5) / 6;
       if (s->NT > 11) { s->use_la = false; s->NT = 16; s->NW = 4; }   // falls back to the two-barrier kernel
       else s->n_pad = 16 * 6 * s->NT;
+      // More trait tiles than CUs (one workgroup per CU): the last round of workgroups leaves CUs idle.  Cut the
+      // SNP axis into segments and the tiles into stream groups whose segment boundaries are staggered, so that
+      // one group's partial last round overlaps another group's full rounds; stream order keeps segment s of a
+      // tile behind its segment s-1 (each segment starts from a complete residual).
+      // (measured on MI355X: no gain over a single launch -- the chip is power/clock limited when every CU issues
+      //  f64 MFMAs, and a partial last round runs correspondingly faster -- so this stays off unless requested)
+      if (const char *e = getenv("AQ_NSEG")) s->nseg = atoi(e) > 0 ? atoi(e) : 1;
+      if (const char *e = getenv("AQ_NGROUP")) s->ngroup = atoi(e) > 0 && atoi(e) <= 4 ? atoi(e) : 1;
+      if (s->nseg > s->nb) s->nseg = s->nb;
+      if (s->nseg > 16) s->nseg = 16;
     }
   }
   if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
@@ -326,6 +382,11 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 3 ? 3 : 1;
   else if (s->NW == 4 && s->ntile > 512) s->TT = 3;
   if (s->NW != 4 || s->use_la) s->TT = 1;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, pr->device) == hipSuccess && prop.multiProcessorCount > 0) s->ncu = prop.multiProcessorCount;
+    if (const char *e = getenv("AQ_NCU")) s->ncu = atoi(e) > 0 ? atoi(e) : s->ncu;
+  }
   int rc = aq_probe_dmode(&s->dmode);
   if (rc != AQ_OK) { delete s; return rc; }
 
@@ -360,7 +421,14 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   double **qv[] = {&s->eta_h, &s->kappa_h, &s->n0, &s->nobs, &s->zeta, &s->tau, &s->sig2b, &s->log_tau, &s->eta_vb,
                    &s->kappa_vb, &s->coef, &s->inv2s, &s->cst};
   for (double **qp : qv) AQ_TRYF(aq_dalloc(qp, (size_t)s->q_pad));
-  AQ_TRYF(aq_dalloc(&s->sums, (size_t)5 * s->q_pad));
+  AQ_TRYF(aq_dalloc(&s->sums, (size_t)5 * s->q_pad * (s->nseg + 1)));
+  for (int gi = 0; gi < s->ngroup && s->ngroup > 1; gi++) {
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);            // lo = lowest priority (numerically greatest)
+    AQ_HIPF(hipStreamCreateWithPriority(&s->gstream[gi], hipStreamNonBlocking, gi == 0 ? hi : lo));
+    AQ_HIPF(hipEventCreateWithFlags(&s->ev_join[gi], hipEventDisableTiming));
+  }
+  if (s->ngroup > 1) AQ_HIPF(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   AQ_TRYF(aq_dalloc(&s->rowA, (size_t)s->ntile * s->p_pad));
   AQ_TRYF(aq_dalloc(&s->rowGB, (size_t)s->ntile * s->p_pad));
   AQ_TRYF(aq_dalloc(&s->Aarr, (size_t)s->ntile * s->p_pad * 16));
@@ -840,6 +908,8 @@ extern "C" int aq_special_eval(int32_t which, const double *x, const double *x2,
         out[i] = aq_gamma_inc_upper(x2[i], x[i]);
         break;
       case 4: out[i] = aq_sigmoid_neg(x[i]); break;
+      case 5: { double a_, b_; aq_log_ndtr_pair(x[i], &a_, &b_); out[i] = a_; } break;
+      case 6: { double a_, b_; aq_log_ndtr_pair(x[i], &a_, &b_); out[i] = b_; } break;
       default: return aq_fail(AQ_ERR_ARG, "aq_special_eval: unknown function id");
     }
   }

@@ -167,7 +167,8 @@ int aq_vb_get_result(aq_vb_handle h, double *beta_vb, double *gam_vb, double *mu
 /* ------------------------------------------------------------------------------------------
  * Test hooks for the fp64 special functions the path uses (host evaluation of the same
  * header the kernels compile): which = 0 log_ndtr, 1 digamma, 2 expint_E1 (x<=1),
- * 3 gamma_inc_upper(a=x2, x), 4 sigmoid_neg.  Evaluates elementwise into out.
+ * 3 gamma_inc_upper(a=x2, x), 4 sigmoid_neg, 5 / 6 log Phi / log(1-Phi) from the one-erfc pair.
+ * Evaluates elementwise into out.
  * ---------------------------------------------------------------------------------------- */
 int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len);
 /* exp(x) E1(x) for a vector with the reference's shared Lentz stopping rule (R/utils.R:380-423);

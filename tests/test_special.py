@@ -25,6 +25,14 @@ def test_log_ndtr_both_tails():
     assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)) < 5e-14
 
 
+def test_log_ndtr_pair_one_erfc():
+    x = np.concatenate([np.linspace(-60, 60, 4001), [-37.0, 37.0, 0.0, 1e-300, -1e-300]])
+    for which, ref in ((5, sp.log_ndtr(x)), (6, sp.log_ndtr(-x))):
+        got = ev(which, x)
+        # (erfc's far tail, where log Phi ~ -1e-262, is good to ~6e-14 relative in glibc)
+        assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)) < 2e-13
+
+
 def test_digamma():
     x = np.concatenate([np.geomspace(1e-3, 1e6, 500), [0.5, 1.0, 1.01, 9.99, 10.0, 505.0]])
     assert np.max(np.abs(ev(1, x) - sp.digamma(x)) / np.maximum(np.abs(sp.digamma(x)), 1e-3)) < 1e-13

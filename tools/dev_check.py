@@ -48,6 +48,9 @@ if __name__ == "__main__":
         parity(1000, 800, 100)
     if what in ("all", "timing"):
         timing(1000, 5000, 1000)
+    if what == "tiles":
+        for q in (1024, 2048, 4096, 4112, 6144, 8192, 10000, 12288):
+            timing(1000, 3200, q, sweeps=3)
     if what == "c3":
         timing(1000, 50000, 10000, sweeps=3)
     if what == "mid":
