@@ -34,6 +34,11 @@ sys.path.insert(0, ROOT)
 # (MI355X_MICROARCH.md has no FP64 row) -- see DESIGN.md section 6.
 PEAK_FP64_SPEC_TFLOPS = 78.6
 PEAK_FP64_MFMA_MEASURED_TFLOPS = 47.7
+# HBM-side bytes of ONE core-sweep launch at the default workload on one GPU, from separate
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command with the gfx950
+# correction (FETCH_SIZE x 2 for coalesced streaming reads, calibrated on aq_k_prepass's gam read):
+# profiles/r01_pmc_hbm_traffic.txt.  PMC counters cannot be read from inside the timed run.
+PMC_TRAFFIC_C3_BYTES = 4.52e10
 
 
 def build_problem(n, p, q_total, k0, k1, device, seed=123):
@@ -135,6 +140,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--to-tol", action="store_true",
+                    help="also run the reference's default run (tol 0.1, maxit 1000) to convergence and report its wall-clock")
     args = ap.parse_args()
 
     import torch
@@ -210,9 +217,12 @@ def main():
                                    f"anneal=(1,2,10) on, horseshoe global-local, sweeps {st0['it'] + 1}-{st1['it']}",
                        "n": n, "p": p, "q": q, "q_per_gpu": q_loc, "parallelism": f"trait-sharded x{world}",
                        "elbo_evals_in_timed_region": st1["n_elbo"] - st0["n_elbo"], "setup_s": round(t_setup, 1)},
-            "roofline": {"bound": "mfma", "kernel": "aq_core_sweep_kernel", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "aq_core_sweep_la_kernel", "achieved": achieved,
                          "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,
-                         "traffic": None, "peak_measured_mfma_f64": PEAK_FP64_MFMA_MEASURED_TFLOPS,
+                         "traffic": PMC_TRAFFIC_C3_BYTES if (n, p, q, world) == (1000, 50000, 10000, 1) else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.txt)",
+                         "algorithmic_bytes": 32.0 * p * q_loc + 8.0 * n * p + 16.0 * n * q_loc,
+                         "peak_measured_mfma_f64": PEAK_FP64_MFMA_MEASURED_TFLOPS,
                          "frac_of_measured_mfma_peak": achieved / PEAK_FP64_MFMA_MEASURED_TFLOPS,
                          "kernel_ms_avg": core_ms, "flop_per_launch": flop_per_launch},
         }
@@ -222,6 +232,19 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
+        if args.to_tol and world == 1:
+            run.close()
+            X2, Y2, lh2, li2 = build_problem(n, p, q, 0, q, local_rank)
+            r2 = VbRun(Y2, X2, lh2, li2, anneal, tol=0.1, maxit=1000, thinned_elbo_eval=True, debug=True,
+                       device=local_rank, q_total=q)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            r2.run()
+            torch.cuda.synchronize()
+            st2 = r2.status()
+            out["elbo_to_tol"] = {"seconds": time.perf_counter() - t1, "it": st2["it"], "converged": bool(st2["converged"]),
+                                  "tol": 0.1, "maxit": 1000, "lb_opt": st2["lb_opt"]}
+            r2.close()
         print(json.dumps(out), flush=True)
     run.close()
     if pg is not None:
