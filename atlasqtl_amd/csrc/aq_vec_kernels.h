@@ -230,6 +230,8 @@ struct AqQvec {
   int nchunk;
   int q, q_pad, n;
   double nu_h, rho_h;
+  int na;   // 1: Y has missing values: kappa uses the X_norm_sq form (R/update_vb.R:150-155), sums[2] = sum_j X_norm_sq (m2 - beta^2),
+            //    sums[5] = sum_j gam log sig2_beta_jk (sig2_beta_vb is p x q, R/update_vb.R:45)
 };
 
 // S1-S8: R/atlasqtl_global_local_core.R:134-150 with R/update_vb.R:116-159,33-50.
@@ -256,7 +258,8 @@ __global__ void aq_k_qpre(AqQvec v, AqScalars *sc, double c) {
   double sg = S[k], sm2 = S[Q + k], sb2 = S[2 * Q + k], rn = S[4 * Q + k];
   double nm1 = (double)(v.n - 1);
   double eta_vb = c * (v.eta_h[k] + v.nobs[k] / 2 + sg / 2) - c + 1;                       // update_eta_vb_
-  double kappa_vb = c * (v.kappa_h[k] + (rn + (nm1 + sig2_inv) * sm2 - nm1 * sb2) / 2);    // update_kappa_vb_
+  double kappa_vb = v.na ? c * (v.kappa_h[k] + (rn + sig2_inv * sm2 + sb2) / 2)
+                         : c * (v.kappa_h[k] + (rn + (nm1 + sig2_inv) * sm2 - nm1 * sb2) / 2);    // update_kappa_vb_
   double tau = eta_vb / kappa_vb;                                                          // :145
   double s2b = 1.0 / (c * (nm1 + sig2_inv) * tau);                                         // update_sig2_beta_vb_
   double log_tau = aq_digamma(eta_vb) - log(kappa_vb);                                     // update_log_tau_vb_
@@ -521,11 +524,12 @@ __global__ void aq_k_elbo_q(AqQvec v, const AqScalars *sc, const double *Hpart, 
   for (int k = threadIdx.x; k < v.q; k += blockDim.x) {
     double sg = v.sums[k], sm2 = v.sums[Q + k], sb2 = v.sums[2 * Q + k], rn = v.sums[4 * Q + k];
     double eta_e = v.eta_h[k] + v.nobs[k] / 2 + sg / 2;
-    double kappa_e = v.kappa_h[k] + (rn + (nm1 + sig2_inv) * sm2 - nm1 * sb2) / 2;
+    double kappa_e = v.na ? v.kappa_h[k] + (rn + sig2_inv * sm2 + sb2) / 2
+                          : v.kappa_h[k] + (rn + (nm1 + sig2_inv) * sm2 - nm1 * sb2) / 2;
     double log_tau_e = aq_digamma(eta_e) - log(kappa_e);
     double tau = v.tau[k];
     s1 += log_tau_e * sg;
-    s2 += sg * (log(v.sig2b[k]) + 1);
+    s2 += v.na ? (v.sums[5 * Q + k] + sg) : sg * (log(v.sig2b[k]) + 1);   // sum_j gam_jk (log sig2_beta + 1), R/elbo.R:28-32
     A += v.nobs[k] * (log_tau_e - 1.8378770664093454835606594728112 /* log(2 pi) */) / 2
          - tau * (kappa_e - sm2 * sig2_inv / 2 - v.kappa_h[k]);                                   // e_y_, R/elbo.R:135-146
     E += (v.eta_h[k] - eta_e) * log_tau_e - (v.kappa_h[k] - kappa_e) * tau + v.eta_h[k] * log(v.kappa_h[k])

@@ -17,6 +17,7 @@
 #include "aq_core_sweep_la.h"
 #include "aq_gram_loop.h"
 #include "aq_special.h"
+#include "aq_trait_wave.h"
 #include "aq_vec_kernels.h"
 
 // ------------------------------------------------------------------ errors ----
@@ -133,6 +134,9 @@ struct aq_vb {
   double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
   int TT = 1;
   bool use_la = false;   // look-ahead kernel (aq_core_sweep_la.h)
+  bool use_tw = false;   // generic wave-per-trait kernel (aq_trait_wave.h): missing Y, or n beyond the MFMA kernels
+  int NE = 0;            // samples per lane of the generic kernel
+  double *Xcm = nullptr, *mis = nullptr, *XN = nullptr;
   int ncu = 256;
   int nseg = 1, ngroup = 1; // SNP segments x trait-tile groups (streams) of the full-sweep launches
   hipStream_t gstream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -166,7 +170,7 @@ struct aq_vb {
 static void aq_free_all(aq_vb *s) {
   if (!s) return;
   hipSetDevice(s->device);
-  void *ptrs[] = {s->XA, s->XU, s->G, s->Gx, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
+  void *ptrs[] = {s->Xcm, s->mis, s->XN, s->XA, s->XU, s->G, s->Gx, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
                   s->eta_h, s->kappa_h, s->n0, s->nobs, s->zeta, s->tau, s->sig2b, s->log_tau, s->eta_vb, s->kappa_vb,
                   s->coef, s->inv2s, s->cst, s->sums, s->rowA, s->rowGB, s->Aarr, s->Barr, s->colApart, s->Hpart, s->sc};
   for (void *ptr : ptrs)
@@ -206,6 +210,24 @@ static std::vector<double> aq_ladder(const double anneal[3]) {
   return l;
 }
 
+static int aq_launch_tw(aq_vb *s, int mode, double c) {
+  AqTwArgs t;
+  t.X = s->Xcm; t.R = s->R; t.mis = s->mis; t.XN = s->XN; t.gam = s->gam; t.mu = s->mu; t.Aarr = s->Aarr; t.Barr = s->Barr;
+  t.tau = s->tau; t.log_tau = s->log_tau; t.sig2b = s->sig2b; t.sc = s->sc; t.sums = s->sums; t.rowGB = s->rowGB; t.c = c;
+  t.n = s->n; t.p = s->p; t.q = s->q; t.n_pad = s->n_pad; t.p_pad = s->p_pad; t.q_pad = s->q_pad; t.ntile = s->ntile;
+  t.mode = mode; t.complete = s->has_missing ? 0 : 1;
+  size_t lds = (size_t)(4 * s->n_pad + 8 * 256) * sizeof(double);
+#define AQ_TW(NE_)                                                                                             \
+  if (s->NE == NE_) {                                                                                          \
+    AQ_HIP(hipFuncSetAttribute((const void *)aq_trait_wave_kernel<NE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((aq_trait_wave_kernel<NE_>), dim3(s->ntile), dim3(1024), lds, 0, t);                   \
+  } else
+  AQ_TW(4) AQ_TW(8) AQ_TW(16) AQ_TW(32) { return aq_fail(AQ_ERR_UNSUPPORTED, "no generic kernel instantiation for this n"); }
+#undef AQ_TW
+  AQ_HIP(hipGetLastError());
+  return AQ_OK;
+}
+
 static int aq_launch_core(aq_vb *s, int mode, double c) {
   AqCoreArgs a;
   a.XA = s->XA; a.XU = s->XU; a.G = s->G; a.Gx = s->Gx; a.R = s->R; a.gam = s->gam; a.mu = s->mu;
@@ -219,7 +241,9 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   AQ_HIP(hipEventCreate(&e0));
   AQ_HIP(hipEventCreate(&e1));
   AQ_HIP(hipEventRecord(e0, 0));
-  if (s->use_la) {
+  if (s->use_tw) {
+    AQ_TRY(aq_launch_tw(s, mode, c));
+  } else if (s->use_la) {
     dim3 blockl(7 * 64);
     a.tile_first = 0; a.b_begin = 0; a.b_end = s->nb; a.sums_slot = 0;
     auto launch = [&](int t_lo, int t_hi, int b0, int b1, int slot, hipStream_t st) -> int {
@@ -295,6 +319,7 @@ static AqQvec aq_qvec(aq_vb *s) {
   v.kappa_vb = s->kappa_vb; v.coef = s->coef; v.inv2s = s->inv2s; v.cst = s->cst; v.sums = s->sums;
   v.colApart = s->colApart; v.nchunk = s->nHchunk;
   v.q = s->q; v.q_pad = s->q_pad; v.n = s->n; v.nu_h = s->nu; v.rho_h = s->rho;
+  v.na = s->has_missing ? 1 : 0;
   return v;
 }
 static AqPvec aq_pvec(aq_vb *s) {
@@ -331,9 +356,8 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     if (!(pr->X[i] == pr->X[i])) return aq_fail(AQ_ERR_ARG, "X must be a non-empty a numeric matrix, finite without missing value.");
   bool has_missing = false;
   for (size_t i = 0; i < nq && !has_missing; i++) has_missing = !(pr->Y[i] == pr->Y[i]);
-  if (has_missing)
-    return aq_fail(AQ_ERR_UNSUPPORTED,
-                   "missing values in Y are not handled by the n-space device path yet (use aq_core_dual_mis_loop at operator level)");
+  if (has_missing && pr->n > 2048)
+    return aq_fail(AQ_ERR_UNSUPPORTED, "missing values in Y with n > 2048 are not handled by the device path yet");
 
   aq_vb *s = new aq_vb();
   s->device = pr->device;
@@ -350,12 +374,16 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   else if (pr->n <= 2048) { s->NT = 16; s->NW = 8; }
   else {
     delete s;
-    return aq_fail(AQ_ERR_UNSUPPORTED, "n > 2048: the register-resident residual tile does not fit (not implemented yet)");
+    return aq_fail(AQ_ERR_UNSUPPORTED, "n > 2048: the register-resident residual does not fit (not implemented yet)");
   }
   {
-    // default: look-ahead kernel (NW = number of matrix waves); AQ_KERNEL=1 selects the two-barrier kernel
+    // default: look-ahead kernel; AQ_KERNEL=1 selects the two-barrier MFMA kernel, AQ_KERNEL=2 the generic one
     const char *ek = getenv("AQ_KERNEL");
-    bool want_la = !(ek && atoi(ek) == 1);
+    if (has_missing || (ek && atoi(ek) == 2) || pr->n > 1056) {
+      s->use_tw = true;
+      s->NE = pr->n <= 256 ? 4 : pr->n <= 512 ? 8 : pr->n <= 1024 ? 16 : 32;
+    }
+    bool want_la = !s->use_tw && !(ek && atoi(ek) == 1);
     if (want_la && pr->n <= 1024) {
       // 6 matrix waves x NT residual tiles each (n padded to 96 NT samples) + the recurrence wave
       s->use_la = true;
@@ -377,6 +405,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     }
   }
   if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
+  if (s->use_tw) s->n_pad = 64 * s->NE;
   // trait tiles per workgroup: 1 (two workgroups per CU) unless that would need a second round of workgroups
   s->TT = 1;
   if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 3 ? 3 : 1;
@@ -403,11 +432,15 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
 #define AQ_HIPF(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { aq_fail(AQ_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); return fail(AQ_ERR_DEVICE); } } while (0)
 
   const int NTT = s->n_pad / 16;
-  size_t xelems = (size_t)s->nb * NTT * 128;
+  size_t xelems = s->use_tw ? 1 : (size_t)s->nb * NTT * 128;
   AQ_TRYF(aq_dalloc(&s->XA, xelems));
   AQ_TRYF(aq_dalloc(&s->XU, xelems));
   AQ_TRYF(aq_dalloc(&s->G, (size_t)s->nb * 256));
   AQ_TRYF(aq_dalloc(&s->Gx, (size_t)s->nb * 256));
+  if (s->use_tw) {
+    AQ_TRYF(aq_dalloc(&s->mis, (size_t)s->ntile * s->n_pad * 16));
+    AQ_TRYF(aq_dalloc(&s->XN, (size_t)s->ntile * s->p_pad * 16));
+  }
   AQ_TRYF(aq_dalloc(&s->R, (size_t)s->ntile * s->n_pad * 16));
   AQ_TRYF(aq_dalloc(&s->gam, (size_t)s->ntile * s->p_pad * 16));
   AQ_TRYF(aq_dalloc(&s->mu, (size_t)s->ntile * s->p_pad * 16));
@@ -448,11 +481,15 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     double *Xd = nullptr;
     AQ_HIPF(hipMalloc((void **)&Xd, np * sizeof(double)));
     AQ_HIPF(hipMemcpy(Xd, pr->X, np * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(aq_k_build_x_layouts, dim3((unsigned)((xelems + 255) / 256)), dim3(256), 0, 0, Xd, s->XA, s->XU,
-                       s->n, s->p, s->nb, NTT, s->dmode);
-    hipLaunchKernelGGL(aq_k_gram_blocks, dim3(s->nb), dim3(256), 0, 0, Xd, s->G, s->Gx, s->n, s->p);
-    AQ_HIPF(hipDeviceSynchronize());
-    AQ_HIPF(hipFree(Xd));
+    if (s->use_tw) {
+      s->Xcm = Xd;   // the generic kernel reads X column-major as given
+    } else {
+      hipLaunchKernelGGL(aq_k_build_x_layouts, dim3((unsigned)((xelems + 255) / 256)), dim3(256), 0, 0, Xd, s->XA, s->XU,
+                         s->n, s->p, s->nb, NTT, s->dmode);
+      hipLaunchKernelGGL(aq_k_gram_blocks, dim3(s->nb), dim3(256), 0, 0, Xd, s->G, s->Gx, s->n, s->p);
+      AQ_HIPF(hipDeviceSynchronize());
+      AQ_HIPF(hipFree(Xd));
+    }
   }
   {
     size_t big = pr->init_on_device ? nq : std::max((size_t)pr->p * pr->q, nq);
@@ -462,6 +499,14 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->n_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->R,
                        s->n, s->q, s->n_pad, 1);
     AQ_HIPF(hipDeviceSynchronize());
+    if (s->use_tw) {   // mis_pat <- ifelse(is.na(Y), 0, 1), R/atlasqtl_global_local_core.R:21
+      std::vector<double> mk(nq);
+      for (size_t i = 0; i < nq; i++) mk[i] = (pr->Y[i] == pr->Y[i]) ? 1.0 : 0.0;
+      AQ_HIPF(hipMemcpy(stage, mk.data(), nq * sizeof(double), hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->n_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->mis,
+                         s->n, s->q, s->n_pad, 0);
+      AQ_HIPF(hipDeviceSynchronize());
+    }
     size_t pq = (size_t)pr->p * pr->q;
     const double *gsrc = pr->gam_vb, *msrc = pr->mu_beta_vb;
     if (!pr->init_on_device) {
@@ -490,7 +535,11 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   AQ_TRYF(aq_upload_padded(s->sig2b, pr->sig2_beta_vb, s->q, s->q_pad));
   {
     std::vector<double> nobs(s->q_pad, 0.0);
-    for (int k = 0; k < s->q; k++) nobs[k] = (double)s->n;   // colSums(mis_pat); complete Y here
+    for (int k = 0; k < s->q; k++) {                          // colSums(mis_pat), R/update_vb.R:132
+      double cnt = 0;
+      for (int i = 0; i < s->n; i++) cnt += (pr->Y[(size_t)i + (size_t)s->n * k] == pr->Y[(size_t)i + (size_t)s->n * k]) ? 1.0 : 0.0;
+      nobs[k] = cnt;
+    }
     AQ_HIPF(hipMemcpy(s->nobs, nobs.data(), nobs.size() * sizeof(double), hipMemcpyHostToDevice));
     // padded traits need valid constants for the init-mode core kernel (coef/inv2s/cst unused there)
     std::vector<double> ones(s->q_pad, 1.0);

@@ -70,12 +70,39 @@ def test_golden_fixture_on_gpu():
         np.testing.assert_allclose(got["gam_vb"], z["out_gam_vb"], atol=1e-9)
 
 
-def test_missing_y_reports_unsupported():
-    """NaN in Y: the n-space device path does not handle it yet and must say so (operator-level
-    aq_core_dual_mis_loop does)."""
+def test_missing_values_in_y_match_oracle():
+    """NaN in Y (the reference's coreDualMisLoop branch, src/coreLoop.cpp:91-138, R/atlasqtl_global_local_core.R:19-32):
+    the generic n-space kernel with a masked residual against the oracle's Gram-space restatement."""
     import atlasqtl_amd as A
-    from atlasqtl_amd import _lib
     from tests.test_oracle import load_vb
     z, lh, li, anneal = load_vb("vb_toy_missing")
-    with pytest.raises(_lib.AtlasqtlHipError, match="missing values in Y"):
-        A.atlasqtl_global_local_core_(z["Y"], z["X"], z["Y"].shape[1], anneal, 1, 0.1, 10, 0, lh, li)
+    assert np.isnan(z["Y"]).any()
+    got = A.atlasqtl_global_local_core_(z["Y"], z["X"], z["Y"].shape[1], anneal, 1, 0.1, 1000, 0, lh, li,
+                                        full_output=True, debug=True)
+    assert got["it"] == int(z["out_it"]) and got["converged"]
+    np.testing.assert_allclose(got["elbo_trace"][1], z["out_elbo_lb"], rtol=1e-9)
+    np.testing.assert_allclose(got["mu_beta_vb"], z["out_mu_beta_vb"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(got["gam_vb"], z["out_gam_vb"], atol=1e-9)
+    np.testing.assert_allclose(got["theta_vb"], z["out_theta_vb"], rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("shape,na", [((100, 75, 20), 0.0), ((300, 130, 49), 0.0), ((200, 90, 33), 0.08), ((70, 17, 1), 0.1)])
+def test_generic_kernel_matches_oracle(shape, na, monkeypatch):
+    """The wave-per-trait kernel (forced with AQ_KERNEL=2) on complete and on incomplete Y."""
+    import atlasqtl_amd as A
+    from oracle import atlasqtl_oracle as O
+    from tests.util import make_problem
+    monkeypatch.setenv("AQ_KERNEL", "2")
+    n, p, q = shape
+    prob = make_problem(n, p, q, p_act=min(8, p // 3), prob_assoc=1.0 if q <= 20 else 0.3, na_frac=na)
+    tr = []
+    ref = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, (1, 2, 10), 1, 0.1, 1000, prob["list_hyper"],
+                                        prob["list_init"], trace=tr, full_output=True)
+    got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, (1, 2, 10), 1, 0.1, 1000, 0, prob["list_hyper"],
+                                        prob["list_init"], full_output=True, debug=True)
+    assert got["it"] == ref["it"]
+    lref = np.array([r["lb"] for r in tr if r["lb"] is not None])
+    np.testing.assert_allclose(got["elbo_trace"][1], lref, rtol=1e-9)
+    np.testing.assert_allclose(got["mu_beta_vb"], ref["mu_beta_vb"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], atol=1e-9)
+    np.testing.assert_allclose(got["tau_vb"], ref["tau_vb"], rtol=1e-8)
