@@ -23,8 +23,8 @@ def parity(n, p, q, anneal=(1, 2, 10)):
           f"mu rel {rel(got['mu_beta_vb'], ref['mu_beta_vb']):.2e}; gam abs {np.max(np.abs(got['gam_vb']-ref['gam_vb'])):.2e}; "
           f"theta rel {rel(got['theta_vb'], ref['theta_vb'],1e-6):.2e}; oracle {t_ref:.2f}s gpu {t_gpu:.2f}s core_ms/launch {got['core_ms']/max(got['core_launches'],1):.3f}", flush=True)
 
-def timing(n, p, q, sweeps=6, anneal=(1, 2, 10)):
-    prob = make_problem(n, p, q, p_act=20, prob_assoc=0.2, maf=(0.05, 0.5))
+def timing(n, p, q, sweeps=6, anneal=(1, 2, 10), na_frac=0.0):
+    prob = make_problem(n, p, q, p_act=20, prob_assoc=0.2, maf=(0.05, 0.5), na_frac=na_frac)
     t = time.time()
     run = VbRun(prob["Y"], prob["X"], prob["list_hyper"], prob["list_init"], anneal, 1e-9, 1000)
     t_create = time.time() - t
@@ -51,6 +51,11 @@ if __name__ == "__main__":
     if what == "tiles":
         for q in (1024, 2048, 4096, 4112, 6144, 8192, 10000, 12288):
             timing(1000, 3200, q, sweeps=3)
+    if what == "generic":
+        timing(1000, 5000, 1000)
+        timing(1000, 5000, 1000, na_frac=0.05)
+        timing(1000, 5000, 4096)
+        timing(2000, 3000, 1024)
     if what == "c3":
         timing(1000, 50000, 10000, sweeps=3)
     if what == "mid":
