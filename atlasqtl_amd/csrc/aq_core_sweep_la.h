@@ -5,10 +5,12 @@
 // ~23 dependent fp64 operations per SNP that cannot be shortened -- runs CONCURRENTLY with the
 // matrix work instead of between two barriers:
 //
-//   workgroup = 7 waves: 6 "matrix" waves (each owns exactly NT 16-sample tiles of the residual R_K in VGPRs)
-//             + 1 "recurrence" wave (lane = trait, owns no residual).  The recurrence wave is wave 3: waves i and
-//             i+4 of a workgroup share a SIMD, so wave 3 of 7 has a SIMD to itself -- its chain of dependent fp64
-//             operations would otherwise wait behind every f64 MFMA issued on that SIMD (measured: 2.6x slower)
+//   workgroup = 8 waves: 6 "matrix" waves (each owns exactly NT 16-sample tiles of the residual R_K in VGPRs)
+//             + 1 "recurrence" wave (lane = trait, owns no residual) + 1 "helper" wave (the block's loads, stores and
+//             column sums).  Waves i and i+4 of a workgroup share a SIMD: the recurrence wave is wave 3 and the helper
+//             wave 7, so no f64 MFMA is ever issued on the recurrence wave's SIMD -- its chain of dependent fp64
+//             operations would otherwise wait behind every one of them (measured: 2.6x slower) -- and the six matrix
+//             waves (0,1,2,4,5,6) run a pure MFMA stream on the other three SIMDs
 //   phase b (one barrier per phase):
 //     recurrence wave : SNP block b.   s_j = S'_b[j] - (X_b'X_{b-1} delta_{b-1})[j]      cross-block Gram, precomputed
 //                                            - sum_{i<j} (X_b'X_b)[j,i] delta_i            in-block Gram
@@ -25,7 +27,7 @@
 #include "aq_core_sweep.h"
 
 template <int NT>
-__global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
+__global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
   constexpr int NWM = 6;                        // matrix waves: 0,1,2,4,5,6
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -35,9 +37,8 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   const int g = lane >> 4;
   const int col = lane & 15;
   const int tile = a.tile_first + blockIdx.x;
-  const bool helper = (w < 3) || (w == 4);      // 256 helper threads on matrix waves 0,1,2,4
-  const int hid = w < 3 ? tid : tid - 64;       // 0..255
-  const int hj = (hid >> 4) & 15, hk = hid & 15;
+  const bool helper = (w == 7);                 // helper wave: entry e = lane + 64 r (r = 0..3) <-> (snp e >> 4, trait e & 15)
+  const int hk = lane & 15, hj0 = lane >> 4;
   const int mr = a.dmode ? 1 : 4, mg = a.dmode ? 4 : 1;   // f64 MFMA D row = mr*reg + mg*(lane>>4)
 
   __shared__ double Sp[2][NWM][256];   // partial S' of each matrix wave [snp][trait]
@@ -57,9 +58,13 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   double sig2b_k = 1.0;
   if (helper) {
     sig2b_k = a.sig2b[ktrait];
-    Lred[0][hid] = Lred[1][hid] = Lred[2][hid] = Lred[3][hid] = 0.0;
-    LG[0][hj * 32 + 16 + hk] = 0.0;
-    LG[1][hj * 32 + 16 + hk] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int e = lane + 64 * r, hj = hj0 + 4 * r;
+      Lred[0][e] = Lred[1][e] = Lred[2][e] = Lred[3][e] = 0.0;
+      LG[0][hj * 32 + 16 + hk] = 0.0;
+      LG[1][hj * 32 + 16 + hk] = 0.0;
+    }
   }
 
   if (is_rec) {
@@ -130,6 +135,92 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       }
     }
     __syncthreads();   // matches the matrix waves' barrier before the final sums
+  } else if (helper) {
+    // =========================== helper wave ===============================================
+    // global -> registers a phase ahead -> LDS; stores and column / row sums of finished blocks
+    double st_A[4], st_g[4], st_m[4], st_B[4], st_G[4], st_Gx[4];
+    auto stage_load = [&](int b) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int e = lane + 64 * r;
+        size_t off = tbase + (size_t)(16 * b) * 16 + e;
+        st_A[r] = a.Aarr[off];
+        st_g[r] = a.gam[off];
+        st_m[r] = a.mu[off];
+        st_B[r] = a.Barr[off];
+        st_G[r] = a.G[(size_t)b * 256 + e];
+        st_Gx[r] = a.Gx[(size_t)b * 256 + e];
+      }
+    };
+    auto stage_commit = [&](int par) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int e = lane + 64 * r, hj = hj0 + 4 * r;
+        LA[par][e] = st_A[r];
+        Lm1[par][e] = st_g[r] * st_m[r];
+        LB[par][e] = st_B[r];
+        LG[par][hj * 32 + hk] = st_G[r];
+        LGx[par][e] = st_Gx[r];
+      }
+    };
+    auto finalize = [&](int b, int par) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int e = lane + 64 * r, hj = hj0 + 4 * r;
+        double gm = Lgam[par][e], mu = Lmu[par][e];
+        size_t off = tbase + (size_t)(16 * b) * 16 + e;
+        a.gam[off] = gm;
+        a.mu[off] = mu;
+        const int j = 16 * b + hj;
+        double gb = 0.0;
+        if (kvalid && j < a.p) {
+          double be = gm * mu;
+          gb = gm * LB[par][e];
+          Lred[0][e] += gm;
+          Lred[1][e] += (mu * mu + sig2b_k) * gm;   // update_m2_beta_, R/update_vb.R:19-31
+          Lred[2][e] += be * be;
+          Lred[3][e] += gb;
+        }
+        gb += __shfl_xor(gb, 8, 64);
+        gb += __shfl_xor(gb, 4, 64);
+        gb += __shfl_xor(gb, 2, 64);
+        gb += __shfl_xor(gb, 1, 64);
+        if (hk == 0) a.rowGB[(size_t)tile * a.p_pad + j] = gb;
+      }
+    };
+    if (a.mode == 1) {
+      for (int b = a.b_begin; b < a.b_end; b++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int e = lane + 64 * r, hj = hj0 + 4 * r;
+          size_t off = tbase + (size_t)(16 * b) * 16 + e;
+          double gm = a.gam[off], mu = a.mu[off];
+          double be = gm * mu;                                  // update_beta_vb_, R/update_vb.R:17
+          Ldel[0][e] = be;
+          if (kvalid && (16 * b + hj) < a.p) {
+            Lred[0][e] += gm;
+            Lred[1][e] += (mu * mu + sig2b_k) * gm;             // initial m2_beta, R/atlasqtl_global_local_core.R:113
+            Lred[2][e] += be * be;
+          }
+        }
+        __syncthreads();
+        __syncthreads();
+      }
+    } else {
+      stage_load(a.b_begin);
+      stage_commit(a.b_begin & 1);
+      aq_lds_barrier();   // prologue
+      for (int b = a.b_begin; b < a.b_end; b++) {
+        const int par = b & 1;
+        const bool more = (b + 1 < a.b_end);
+        if (more) stage_load(b + 1);
+        if (b > a.b_begin) finalize(b - 1, par ^ 1);
+        if (more) stage_commit(par ^ 1);
+        aq_lds_barrier();
+      }
+      finalize(a.b_end - 1, (a.b_end - 1) & 1);
+    }
+    __syncthreads();   // matches the matrix waves' barrier before the final sums
   } else {
     // =========================== matrix waves ==============================================
     // residual tiles: Rr[t][r] <-> sample 16*(my_t0+t) + mr*r + mg*g, trait col
@@ -143,46 +234,6 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     const double2 *XAw = a.XA + (size_t)my_t0 * 128 + lane;
     const double2 *XUw = a.XU + (size_t)my_t0 * 128 + lane;
 
-    // ---- helper-thread staging (global -> registers a phase ahead -> LDS)
-    double st_A = 0, st_g = 0, st_m = 0, st_B = 0, st_G = 0, st_Gx = 0;
-    auto stage_load = [&](int b) {
-      size_t off = tbase + (size_t)(16 * b) * 16 + hid;
-      st_A = a.Aarr[off];
-      st_g = a.gam[off];
-      st_m = a.mu[off];
-      st_B = a.Barr[off];
-      st_G = a.G[(size_t)b * 256 + hid];
-      st_Gx = a.Gx[(size_t)b * 256 + hid];
-    };
-    auto stage_commit = [&](int par) {
-      LA[par][hid] = st_A;
-      Lm1[par][hid] = st_g * st_m;
-      LB[par][hid] = st_B;
-      LG[par][hj * 32 + hk] = st_G;
-      LGx[par][hid] = st_Gx;
-    };
-    // stores and column / row sums of a finished block (gam, mu, delta in LDS parity `par`)
-    auto finalize = [&](int b, int par) {
-      double gm = Lgam[par][hid], mu = Lmu[par][hid];
-      size_t off = tbase + (size_t)(16 * b) * 16 + hid;
-      a.gam[off] = gm;
-      a.mu[off] = mu;
-      const int j = 16 * b + hj;
-      double gb = 0.0;
-      if (kvalid && j < a.p) {
-        double be = gm * mu;
-        gb = gm * LB[par][hid];
-        Lred[0][hid] += gm;
-        Lred[1][hid] += (mu * mu + sig2b_k) * gm;   // update_m2_beta_, R/update_vb.R:19-31
-        Lred[2][hid] += be * be;
-        Lred[3][hid] += gb;
-      }
-      gb += __shfl_xor(gb, 8, 64);
-      gb += __shfl_xor(gb, 4, 64);
-      gb += __shfl_xor(gb, 2, 64);
-      gb += __shfl_xor(gb, 1, 64);
-      if (hk == 0) a.rowGB[(size_t)tile * a.p_pad + j] = gb;
-    };
     // matrix work of one phase: update with block bu (delta in LDS parity pu) and/or S' of block bs -> Sp[ps]
     auto matrix_phase = [&](bool do_u, int bu, int pu, bool do_s, int bs, int ps) {
       double nd[4];
@@ -228,18 +279,7 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     if (a.mode == 1) {
       // ---------------- init mode: R = Y - X (gam*mu), block by block; column sums of the initial state
       for (int b = a.b_begin; b < a.b_end; b++) {
-        if (helper) {
-          size_t off = tbase + (size_t)(16 * b) * 16 + hid;
-          double gm = a.gam[off], mu = a.mu[off];
-          double be = gm * mu;                                  // update_beta_vb_, R/update_vb.R:17
-          Ldel[0][hid] = be;
-          if (kvalid && (16 * b + hj) < a.p) {
-            Lred[0][hid] += gm;
-            Lred[1][hid] += (mu * mu + sig2b_k) * gm;           // initial m2_beta, R/atlasqtl_global_local_core.R:113
-            Lred[2][hid] += be * be;
-          }
-        }
-        __syncthreads();
+        __syncthreads();                                  // the helper wave has put beta of block b into Ldel[0]
         matrix_phase(true, b, 0, false, 0, 0);
         __syncthreads();
       }
@@ -247,23 +287,14 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       // ---------------- full sweep -----------------------------------------------------
       // prologue: S'_0 from the untouched residual, staging of block 0
       matrix_phase(false, 0, 0, true, a.b_begin, a.b_begin & 1);
-      if (helper) {
-        stage_load(a.b_begin);
-        stage_commit(a.b_begin & 1);
-      }
       aq_lds_barrier();
       for (int b = a.b_begin; b < a.b_end; b++) {
         const int par = b & 1;
         const bool more = (b + 1 < a.b_end);
-        // update with block b-1, S' of block b+1, helper duties
-        if (helper && more) stage_load(b + 1);
+        // update with block b-1, S' of block b+1
 #if !(AQ_DIAG & 2)
         if (b > a.b_begin || more) matrix_phase(b > a.b_begin, b - 1, par ^ 1, more, b + 1, par ^ 1);
 #endif
-        if (helper) {
-          if (b > a.b_begin) finalize(b - 1, par ^ 1);
-          if (more) stage_commit(par ^ 1);
-        }
         aq_lds_barrier();
       }
       // epilogue: the last block's update and stores
@@ -271,7 +302,6 @@ __global__ __launch_bounds__(7 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #if !(AQ_DIAG & 2)
       matrix_phase(true, a.b_end - 1, pl, false, 0, 0);
 #endif
-      if (helper) finalize(a.b_end - 1, pl);
     }
     // ---- write the residual back and ||R_k||^2 partials ----
     double rn = 0.0;

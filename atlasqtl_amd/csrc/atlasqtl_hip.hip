@@ -244,7 +244,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   if (s->use_tw) {
     AQ_TRY(aq_launch_tw(s, mode, c));
   } else if (s->use_la) {
-    dim3 blockl(7 * 64);
+    dim3 blockl(8 * 64);
     a.tile_first = 0; a.b_begin = 0; a.b_end = s->nb; a.sums_slot = 0;
     auto launch = [&](int t_lo, int t_hi, int b0, int b1, int slot, hipStream_t st) -> int {
       if (t_hi <= t_lo || b1 <= b0) return AQ_OK;
