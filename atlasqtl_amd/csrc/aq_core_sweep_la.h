@@ -25,8 +25,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "aq_core_sweep.h"
+#include <type_traits>
 
-template <int NT>
+// NT = residual tiles of matrix waves 0,1,2; NT2 (= NT or NT-1) those of waves 4,5,6: each SIMD carries NT + NT2.
+template <int NT, int NT2>
 __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
   constexpr int NWM = 6;                        // matrix waves: 0,1,2,4,5,6
   const int tid = threadIdx.x;
@@ -224,18 +226,21 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   } else {
     // =========================== matrix waves ==============================================
     // residual tiles: Rr[t][r] <-> sample 16*(my_t0+t) + mr*r + mg*g, trait col
-    constexpr int NTT = NT * NWM;
-    const int my_t0 = mw * NT;
+    constexpr int NTT = 3 * (NT + NT2);
+    const bool hi = mw < 3;                          // owns NT tiles (else NT2)
+    const int my_t0 = hi ? mw * NT : 3 * NT + (mw - 3) * NT2;
     aq_d4 Rr[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) Rr[t][r] = Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col];
+      for (int r = 0; r < 4; r++)
+        Rr[t][r] = (hi || t < NT2) ? Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col] : 0.0;
     const double2 *XAw = a.XA + (size_t)my_t0 * 128 + lane;
     const double2 *XUw = a.XU + (size_t)my_t0 * 128 + lane;
 
     // matrix work of one phase: update with block bu (delta in LDS parity pu) and/or S' of block bs -> Sp[ps]
-    auto matrix_phase = [&](bool do_u, int bu, int pu, bool do_s, int bs, int ps) {
+    auto matrix_phase_n = [&](auto ntc, bool do_u, int bu, int pu, bool do_s, int bs, int ps) {
+      constexpr int NTC = decltype(ntc)::value;
       double nd[4];
       if (do_u) {
 #pragma unroll
@@ -246,9 +251,9 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const double2 *xa = XAw + (size_t)(do_s ? bs : 0) * NTT * 128;
       double2 cu0 = xu[0], cu1 = xu[64], ca0 = xa[0], ca1 = xa[64];
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
+      for (int t = 0; t < NTC; t++) {
         double2 nu0, nu1, na0, na1;
-        if (t + 1 < NT) {
+        if (t + 1 < NTC) {
           nu0 = xu[(t + 1) * 128]; nu1 = xu[(t + 1) * 128 + 64];
           na0 = xa[(t + 1) * 128]; na1 = xa[(t + 1) * 128 + 64];
         }
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           acc = aq_mfma(ca1.x, Rt[2], acc);
           acc = aq_mfma(ca1.y, Rt[3], acc);
         }
-        if (t + 1 < NT) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
+        if (t + 1 < NTC) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (do_s) {
@@ -274,7 +279,10 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         for (int i = 0; i < 4; i++) Sp[ps][mw][(mr * i + mg * g) * 16 + col] = acc[i];
       }
     };
-
+    auto matrix_phase = [&](bool do_u, int bu, int pu, bool do_s, int bs, int ps) {
+      if (NT2 == NT || hi) matrix_phase_n(std::integral_constant<int, NT>{}, do_u, bu, pu, do_s, bs, ps);
+      else matrix_phase_n(std::integral_constant<int, NT2>{}, do_u, bu, pu, do_s, bs, ps);
+    };
 
     if (a.mode == 1) {
       // ---------------- init mode: R = Y - X (gam*mu), block by block; column sums of the initial state
@@ -309,9 +317,11 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     for (int t = 0; t < NT; t++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        double v = Rr[t][r];
-        Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col] = v;
-        rn += v * v;
+        if (hi || t < NT2) {
+          double v = Rr[t][r];
+          Rg[(size_t)(16 * (my_t0 + t) + mr * r + mg * g) * 16 + col] = v;
+          rn += v * v;
+        }
       }
     Lrn[mw * 4 + g][col] = rn;
     __syncthreads();

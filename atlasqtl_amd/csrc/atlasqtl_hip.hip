@@ -134,6 +134,7 @@ struct aq_vb {
   double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
   int TT = 1;
   bool use_la = false;   // look-ahead kernel (aq_core_sweep_la.h)
+  int NT2 = 0;           // look-ahead kernel: tiles of matrix waves 4,5,6 (NT: waves 0,1,2)
   bool use_tw = false;   // generic wave-per-trait kernel (aq_trait_wave.h): missing Y, or n beyond the MFMA kernels
   int NE = 0;            // samples per lane of the generic kernel
   double *Xcm = nullptr, *mis = nullptr, *XN = nullptr;
@@ -251,9 +252,11 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
       AqCoreArgs b = a;
       b.tile_first = t_lo; b.b_begin = b0; b.b_end = b1; b.sums_slot = slot;
       dim3 gridl(t_hi - t_lo);
-#define AQ_LA(NT_)                                                                   \
-  if (s->NT == NT_) {                                                                \
-    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_>), gridl, blockl, 0, st, b);     \
+#define AQ_LA(NT_)                                                                             \
+  if (s->NT == NT_ && s->NT2 == NT_) {                                                         \
+    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, NT_>), gridl, blockl, 0, st, b);          \
+  } else if (s->NT == NT_ && s->NT2 == NT_ - 1 && NT_ > 1) {                                   \
+    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, (NT_ > 1 ? NT_ - 1 : 1)>), gridl, blockl, 0, st, b); \
   } else
       AQ_LA(1) AQ_LA(2) AQ_LA(3) AQ_LA(4) AQ_LA(5) AQ_LA(6) AQ_LA(7) AQ_LA(8) AQ_LA(9) AQ_LA(10) AQ_LA(11) {
         return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
@@ -389,9 +392,13 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       s->use_la = true;
       const int ntiles = (pr->n + 15) / 16;
       s->NW = 6;
-      s->NT = (ntiles + 5) / 6;
+      // per SIMD (waves w and w+4): NT + NT2 tiles, NT2 = NT or NT - 1  ->  n padded to 48 (NT + NT2) samples
+      const int per_simd = (ntiles + 2) / 3;
+      s->NT = (per_simd + 1) / 2;
+      s->NT2 = per_simd - s->NT;
+      if (s->NT2 < 1) s->NT2 = s->NT;
       if (s->NT > 11) { s->use_la = false; s->NT = 16; s->NW = 4; }   // falls back to the two-barrier kernel
-      else s->n_pad = 16 * 6 * s->NT;
+      else s->n_pad = 16 * 3 * (s->NT + s->NT2);
       // More trait tiles than CUs (one workgroup per CU): the last round of workgroups leaves CUs idle.  Cut the
       // SNP axis into segments and the tiles into stream groups whose segment boundaries are staggered, so that
       // one group's partial last round overlaps another group's full rounds; stream order keeps segment s of a
