@@ -61,8 +61,9 @@ AQ_HD double aq_sigmoid_neg(double x) {
 
 // digamma for x > 0: upward recurrence to x >= 10, then the asymptotic series.
 AQ_HD double aq_digamma(double x) {
+  if (!(x > 0.0)) return NAN;          // the path only calls it with positive arguments; never loop on garbage
   double acc = 0.0;
-  while (x < 10.0) {
+  for (int i = 0; i < 10 && x < 10.0; i++) {   // at most 10 steps for x > 0
     acc -= 1.0 / x;
     x += 1.0;
   }

@@ -38,6 +38,11 @@ def test_digamma():
     assert np.max(np.abs(ev(1, x) - sp.digamma(x)) / np.maximum(np.abs(sp.digamma(x)), 1e-3)) < 1e-13
 
 
+def test_digamma_never_spins_on_bad_input():
+    out = ev(1, np.array([-1e300, -3.0, 0.0, np.nan]))
+    assert np.all(np.isnan(out))
+
+
 def test_expint_e1_small():
     x = np.geomspace(1e-12, 1.0, 400)
     assert np.max(np.abs(ev(2, x) - sp.exp1(x)) / sp.exp1(x)) < 5e-15
