@@ -62,6 +62,9 @@ struct AqCoreArgs {
   int tile_first;        // look-ahead kernel: first trait tile of this launch
   int b_begin, b_end;    // look-ahead kernel: SNP blocks [b_begin, b_end) handled by this launch (one segment)
   int sums_slot;         // per-segment slot of the column sums: sums[slot][5][q_pad]
+  int nseg;              // > 1: chained-segment launch, block s*ntile + k = SNP segment s of trait tile k
+  int *done;             // chained segments: done[tile] = number of that tile's segments already finished
+  int *errflag;          // set when a bounded wait on done[] expires (results invalid, reported to the host)
   int wt_base[16];       // look-ahead kernel: first residual tile of each matrix wave ...
   int wt_cnt[16];        // ... and how many it owns (uneven: the wave sharing a SIMD with the recurrence wave gets fewer)
 };

@@ -28,7 +28,12 @@
 #include <type_traits>
 
 // NT = residual tiles of matrix waves 0,1,2; NT2 (= NT or NT-1) those of waves 4,5,6: each SIMD carries NT + NT2.
-template <int NT, int NT2>
+// SEG: chained-segment launch (a.nseg * a.ntile workgroups).  Workgroup s*ntile + k handles SNP segment s of trait
+// tile k, starting from the residual that segment s-1 of the same tile left in global memory.  Blocks are dispatched
+// in index order, so that workgroup has normally finished long before; correctness does not depend on it: the
+// hand-off is an agent-scope release (producer) / acquire (consumer) around done[k], and the wait is bounded.
+// With one workgroup per CU this turns 625 tiles on 256 CUs from 3 whole rounds into 2.44 + rounding.
+template <int NT, int NT2, bool SEG>
 __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
   constexpr int NWM = 6;                        // matrix waves: 0,1,2,4,5,6
   const int tid = threadIdx.x;
@@ -38,7 +43,27 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   const int mw = w < 3 ? w : w - 1;             // matrix-wave index 0..5
   const int g = lane >> 4;
   const int col = lane & 15;
-  const int tile = a.tile_first + blockIdx.x;
+  int tile_ = a.tile_first + blockIdx.x, seg_b0 = a.b_begin, seg_b1 = a.b_end, seg_slot = a.sums_slot, seg = 0;
+  if (SEG) {
+    seg = blockIdx.x / a.ntile;
+    tile_ = blockIdx.x - seg * a.ntile;
+    seg_b0 = (int)((long long)a.nb * seg / a.nseg);
+    seg_b1 = (int)((long long)a.nb * (seg + 1) / a.nseg);
+    seg_slot = seg;
+    if (seg > 0) {
+      if (tid == 0) {
+        int tries = 0;
+        while (__hip_atomic_load(&a.done[tile_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+          __builtin_amdgcn_s_sleep(32);
+          if (++tries > 4000000) { *a.errflag = 1; break; }   // bounded: never hang the GPU
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+    }
+  }
+  const int tile = tile_;
   const bool helper = (w == 7);                 // helper wave: entry e = lane + 64 r (r = 0..3) <-> (snp e >> 4, trait e & 15)
   const int hk = lane & 15, hj0 = lane >> 4;
   const int mr = a.dmode ? 1 : 4, mg = a.dmode ? 4 : 1;   // f64 MFMA D row = mr*reg + mg*(lane>>4)
@@ -72,7 +97,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   if (is_rec) {
     // =========================== recurrence wave ===========================================
     if (a.mode == 1) {
-      for (int b = a.b_begin; b < a.b_end; b++) {   // init mode: nothing to do, keep the barrier count
+      for (int b = seg_b0; b < seg_b1; b++) {   // init mode: nothing to do, keep the barrier count
         __syncthreads();
         __syncthreads();
       }
@@ -82,7 +107,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const double rc_cinv2s = a.c * a.inv2s[kk];
       const double rc_cst = a.cst[kk];
       aq_lds_barrier();   // prologue
-      for (int b = a.b_begin; b < a.b_end; b++) {
+      for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
 #if !(AQ_DIAG & 1)
         // ---- SNP block b, lane = trait ---------------------------------------------------
@@ -93,7 +118,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #pragma unroll
           for (int ww = 1; ww < NWM; ww++) s += Sp[par][ww][j * 16 + col];
           S[j] = s;
-          dlp[j] = (b > a.b_begin) ? Ldel[par ^ 1][j * 16 + col] : 0.0;   // delta of block b-1 (a segment starts from a complete residual)
+          dlp[j] = (b > seg_b0) ? Ldel[par ^ 1][j * 16 + col] : 0.0;   // delta of block b-1 (a segment starts from a complete residual)
         }
         // cross-block correction of the first SNP; the others follow inside the loop, one row ahead
 #pragma unroll
@@ -191,7 +216,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       }
     };
     if (a.mode == 1) {
-      for (int b = a.b_begin; b < a.b_end; b++) {
+      for (int b = seg_b0; b < seg_b1; b++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int e = lane + 64 * r, hj = hj0 + 4 * r;
@@ -209,18 +234,18 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         __syncthreads();
       }
     } else {
-      stage_load(a.b_begin);
-      stage_commit(a.b_begin & 1);
+      stage_load(seg_b0);
+      stage_commit(seg_b0 & 1);
       aq_lds_barrier();   // prologue
-      for (int b = a.b_begin; b < a.b_end; b++) {
+      for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
-        const bool more = (b + 1 < a.b_end);
+        const bool more = (b + 1 < seg_b1);
         if (more) stage_load(b + 1);
-        if (b > a.b_begin) finalize(b - 1, par ^ 1);
+        if (b > seg_b0) finalize(b - 1, par ^ 1);
         if (more) stage_commit(par ^ 1);
         aq_lds_barrier();
       }
-      finalize(a.b_end - 1, (a.b_end - 1) & 1);
+      finalize(seg_b1 - 1, (seg_b1 - 1) & 1);
     }
     __syncthreads();   // matches the matrix waves' barrier before the final sums
   } else {
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 
     if (a.mode == 1) {
       // ---------------- init mode: R = Y - X (gam*mu), block by block; column sums of the initial state
-      for (int b = a.b_begin; b < a.b_end; b++) {
+      for (int b = seg_b0; b < seg_b1; b++) {
         __syncthreads();                                  // the helper wave has put beta of block b into Ldel[0]
         matrix_phase(true, b, 0, false, 0, 0);
         __syncthreads();
@@ -294,21 +319,21 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     } else {
       // ---------------- full sweep -----------------------------------------------------
       // prologue: S'_0 from the untouched residual, staging of block 0
-      matrix_phase(false, 0, 0, true, a.b_begin, a.b_begin & 1);
+      matrix_phase(false, 0, 0, true, seg_b0, seg_b0 & 1);
       aq_lds_barrier();
-      for (int b = a.b_begin; b < a.b_end; b++) {
+      for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
-        const bool more = (b + 1 < a.b_end);
+        const bool more = (b + 1 < seg_b1);
         // update with block b-1, S' of block b+1
 #if !(AQ_DIAG & 2)
-        if (b > a.b_begin || more) matrix_phase(b > a.b_begin, b - 1, par ^ 1, more, b + 1, par ^ 1);
+        if (b > seg_b0 || more) matrix_phase(b > seg_b0, b - 1, par ^ 1, more, b + 1, par ^ 1);
 #endif
         aq_lds_barrier();
       }
       // epilogue: the last block's update and stores
-      const int pl = (a.b_end - 1) & 1;
+      const int pl = (seg_b1 - 1) & 1;
 #if !(AQ_DIAG & 2)
-      matrix_phase(true, a.b_end - 1, pl, false, 0, 0);
+      matrix_phase(true, seg_b1 - 1, pl, false, 0, 0);
 #endif
     }
     // ---- write the residual back and ||R_k||^2 partials ----
@@ -331,12 +356,22 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     int k2 = tile * 16 + tid;
     double r2 = 0.0;
     for (int s = 0; s < NWM * 4; s++) r2 += Lrn[s][tid];
-    double *sm = a.sums + (size_t)a.sums_slot * 5 * a.q_pad;
+    double *sm = a.sums + (size_t)seg_slot * 5 * a.q_pad;
     sm[(size_t)4 * a.q_pad + k2] = r2;
     for (int v = 0; v < 4; v++) {
       double acc2 = 0.0;
       for (int jj = 0; jj < 16; jj++) acc2 += Lred[v][jj * 16 + tid];
       sm[(size_t)v * a.q_pad + k2] = acc2;
+    }
+  }
+  if (SEG) {
+    // publish this tile's residual: every storing wave drains its stores, then one agent-scope release + flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&a.done[tile], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -140,6 +140,8 @@ struct aq_vb {
   double *Xcm = nullptr, *mis = nullptr, *XN = nullptr;
   int ncu = 256;
   int nseg = 1, ngroup = 1; // SNP segments x trait-tile groups (streams) of the full-sweep launches
+  int chain = 0;            // > 1: chained-segment launch with that many SNP segments (aq_core_sweep_la.h, SEG)
+  int *done = nullptr, *errflag = nullptr;
   hipStream_t gstream[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   bool pre_done = false;
@@ -187,6 +189,8 @@ static void aq_free_all(aq_vb *s) {
     if (s->ev_join[gi]) hipEventDestroy(s->ev_join[gi]);
   }
   if (s->ev_fork) hipEventDestroy(s->ev_fork);
+  if (s->done) hipFree(s->done);
+  if (s->errflag) hipFree(s->errflag);
   delete s;
 }
 
@@ -247,6 +251,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   } else if (s->use_la) {
     dim3 blockl(8 * 64);
     a.tile_first = 0; a.b_begin = 0; a.b_end = s->nb; a.sums_slot = 0;
+    a.nseg = 1; a.done = s->done; a.errflag = s->errflag;
     auto launch = [&](int t_lo, int t_hi, int b0, int b1, int slot, hipStream_t st) -> int {
       if (t_hi <= t_lo || b1 <= b0) return AQ_OK;
       AqCoreArgs b = a;
@@ -254,9 +259,9 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
       dim3 gridl(t_hi - t_lo);
 #define AQ_LA(NT_)                                                                             \
   if (s->NT == NT_ && s->NT2 == NT_) {                                                         \
-    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, NT_>), gridl, blockl, 0, st, b);          \
+    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, NT_, false>), gridl, blockl, 0, st, b);   \
   } else if (s->NT == NT_ && s->NT2 == NT_ - 1 && NT_ > 1) {                                   \
-    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, (NT_ > 1 ? NT_ - 1 : 1)>), gridl, blockl, 0, st, b); \
+    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, (NT_ > 1 ? NT_ - 1 : 1), false>), gridl, blockl, 0, st, b); \
   } else
       AQ_LA(1) AQ_LA(2) AQ_LA(3) AQ_LA(4) AQ_LA(5) AQ_LA(6) AQ_LA(7) AQ_LA(8) AQ_LA(9) AQ_LA(10) AQ_LA(11) {
         return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
@@ -264,7 +269,26 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
 #undef AQ_LA
       return AQ_OK;
     };
-    if (mode == 1 || (s->nseg <= 1 && s->ngroup <= 1)) {
+    if (mode == 0 && s->chain > 1) {
+      // chained-segment launch: chain * ntile workgroups, block s*ntile + k = segment s of tile k
+      AQ_HIP(hipMemsetAsync(s->done, 0, (size_t)s->ntile * sizeof(int), 0));
+      AqCoreArgs b = a;
+      b.nseg = s->chain;
+      dim3 gridc((unsigned)((long long)s->chain * s->ntile));
+#define AQ_LAC(NT_)                                                                            \
+  if (s->NT == NT_ && s->NT2 == NT_) {                                                         \
+    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, NT_, true>), gridc, blockl, 0, 0, b);     \
+  } else if (s->NT == NT_ && s->NT2 == NT_ - 1 && NT_ > 1) {                                   \
+    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, (NT_ > 1 ? NT_ - 1 : 1), true>), gridc, blockl, 0, 0, b); \
+  } else
+      AQ_LAC(1) AQ_LAC(2) AQ_LAC(3) AQ_LAC(4) AQ_LAC(5) AQ_LAC(6) AQ_LAC(7) AQ_LAC(8) AQ_LAC(9) AQ_LAC(10) AQ_LAC(11) {
+        return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
+      }
+#undef AQ_LAC
+      AQ_HIP(hipMemsetAsync(s->sums + (size_t)s->chain * 5 * s->q_pad, 0, (size_t)5 * s->q_pad * sizeof(double), 0));
+      hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad,
+                         s->chain + 1, s->ntile, 1);
+    } else if (mode == 1 || (s->nseg <= 1 && s->ngroup <= 1)) {
       AQ_TRY(launch(0, s->ntile, 0, s->nb, 0, 0));
     } else {
       const int G = s->ngroup, S = s->nseg;
@@ -405,6 +429,19 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       // tile behind its segment s-1 (each segment starts from a complete residual).
       // (measured on MI355X: no gain over a single launch -- the chip is power/clock limited when every CU issues
       //  f64 MFMAs, and a partial last round runs correspondingly faster -- so this stays off unless requested)
+      // more trait tiles than CUs: chained SNP segments even out the last round (3 rounds -> ~2.5 for 625 tiles)
+      if (s->ntile > s->ncu) {
+        double best = 1e30;
+        for (int S = 2; S <= 16; S++) {   // rounds of workgroups per sweep, in units of whole-sweep rounds
+          long long wg = (long long)s->ntile * S;
+          double cost = (double)((wg + s->ncu - 1) / s->ncu) / S * (1.0 + 0.002 * S);
+          if (cost < best - 1e-12) { best = cost; s->chain = S; }
+        }
+        if (best >= (double)((s->ntile + s->ncu - 1) / s->ncu)) s->chain = 0;   // no gain over whole tiles
+      }
+      if (const char *e = getenv("AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
+      if (s->chain > s->nb) s->chain = s->nb;
+      if (s->chain > 32) s->chain = 32;
       if (const char *e = getenv("AQ_NSEG")) s->nseg = atoi(e) > 0 ? atoi(e) : 1;
       if (const char *e = getenv("AQ_NGROUP")) s->ngroup = atoi(e) > 0 && atoi(e) <= 4 ? atoi(e) : 1;
       if (s->nseg > s->nb) s->nseg = s->nb;
@@ -461,7 +498,9 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   double **qv[] = {&s->eta_h, &s->kappa_h, &s->n0, &s->nobs, &s->zeta, &s->tau, &s->sig2b, &s->log_tau, &s->eta_vb,
                    &s->kappa_vb, &s->coef, &s->inv2s, &s->cst};
   for (double **qp : qv) AQ_TRYF(aq_dalloc(qp, (size_t)s->q_pad));
-  AQ_TRYF(aq_dalloc(&s->sums, (size_t)5 * s->q_pad * (s->nseg + 1)));
+  AQ_TRYF(aq_dalloc(&s->sums, (size_t)5 * s->q_pad * ((s->nseg > s->chain ? s->nseg : s->chain) + 2)));
+  AQ_TRYF(aq_dalloc(&s->done, (size_t)s->ntile));
+  AQ_TRYF(aq_dalloc(&s->errflag, (size_t)1));
   for (int gi = 0; gi < s->ngroup && s->ngroup > 1; gi++) {
     int lo = 0, hi = 0;
     hipDeviceGetStreamPriorityRange(&lo, &hi);            // lo = lowest priority (numerically greatest)
@@ -643,6 +682,17 @@ static int aq_elbo_local(aq_vb *s) {
   return AQ_OK;
 }
 
+static int aq_check_chain_error(aq_vb *s) {
+  if (s->chain <= 1 || !s->errflag) return AQ_OK;
+  int f = 0;
+  AQ_HIP(hipMemcpy(&f, s->errflag, sizeof(int), hipMemcpyDeviceToHost));
+  if (f != 0) {
+    s->failed = true;
+    return aq_fail(AQ_ERR_DEVICE, "chained core sweep: a bounded wait on a tile's previous SNP segment expired (results invalid; set AQ_CHAIN=0)");
+  }
+  return AQ_OK;
+}
+
 static int aq_elbo_finish(aq_vb *s, double *lb) {
   AqElboConst k;
   k.nu_h = s->nu; k.rho_h = s->rho; k.A2_inv = s->A2_inv; k.t02_inv = s->t02_inv;
@@ -652,6 +702,7 @@ static int aq_elbo_finish(aq_vb *s, double *lb) {
   AQ_HIP(hipGetLastError());
   AqScalars h;
   AQ_HIP(hipMemcpy(&h, s->sc, sizeof(h), hipMemcpyDeviceToHost));
+  AQ_TRY(aq_check_chain_error(s));
   *lb = h.elbo;
   return AQ_OK;
 }
@@ -788,6 +839,7 @@ extern "C" int aq_vb_get_status(aq_vb_handle s, aq_vb_status *st) {
   if (!s || !st) return aq_fail(AQ_ERR_ARG, "NULL argument");
   AQ_HIP(hipSetDevice(s->device));
   aq_resolve_events(s);
+  AQ_TRY(aq_check_chain_error(s));
   AqScalars h;
   AQ_HIP(hipMemcpy(&h, s->sc, sizeof(h), hipMemcpyDeviceToHost));
   st->it = s->it;
