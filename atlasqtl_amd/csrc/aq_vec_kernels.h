@@ -275,12 +275,17 @@ __global__ void aq_k_qpre(AqQvec v, AqScalars *sc, double c) {
 
 // ------------------------------------------------------------ reductions ----
 // red[j] = sum over tiles of rowA + rowGB (fixed order) = rowSums(Z), R/update_vb.R:179
+// rowGB holds gb_rows rows per tile (the generic kernel splits a tile over several workgroups), rowA one.
 __global__ void aq_k_reduce_rows(const double *__restrict__ rowA, const double *__restrict__ rowGB,
-                                 double *__restrict__ red, int ntile, int p_pad) {
+                                 double *__restrict__ red, int ntile, int p_pad, int gb_rows) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p_pad) return;
   double s = 0.0;
-  for (int t = 0; t < ntile; t++) s += rowA[(size_t)t * p_pad + j] + rowGB[(size_t)t * p_pad + j];
+  for (int t = 0; t < ntile; t++) {
+    double gb = rowGB[(size_t)t * gb_rows * p_pad + j];
+    for (int r = 1; r < gb_rows; r++) gb += rowGB[((size_t)t * gb_rows + r) * p_pad + j];
+    s += rowA[(size_t)t * p_pad + j] + gb;
+  }
   red[j] = s;
 }
 

@@ -137,6 +137,8 @@ struct aq_vb {
   int NT2 = 0;           // look-ahead kernel: tiles of matrix waves 4,5,6 (NT: waves 0,1,2)
   bool use_tw = false;   // generic wave-per-trait kernel (aq_trait_wave.h): missing Y, or n beyond the MFMA kernels
   int NE = 0;            // samples per lane of the generic kernel
+  int WPT = 1;           // generic kernel: waves (and workgroups) sharing one trait (tile); also rowGB rows per tile
+  int tw_ns = 4;         // generic kernel: SNP columns staged in LDS at a time
   double *Xcm = nullptr, *mis = nullptr, *XN = nullptr;
   int ncu = 256;
   int nseg = 1, ngroup = 1; // SNP segments x trait-tile groups (streams) of the full-sweep launches
@@ -221,13 +223,17 @@ static int aq_launch_tw(aq_vb *s, int mode, double c) {
   t.tau = s->tau; t.log_tau = s->log_tau; t.sig2b = s->sig2b; t.sc = s->sc; t.sums = s->sums; t.rowGB = s->rowGB; t.c = c;
   t.n = s->n; t.p = s->p; t.q = s->q; t.n_pad = s->n_pad; t.p_pad = s->p_pad; t.q_pad = s->q_pad; t.ntile = s->ntile;
   t.mode = mode; t.complete = s->has_missing ? 0 : 1;
-  size_t lds = (size_t)(4 * s->n_pad + 8 * 256) * sizeof(double);
-#define AQ_TW(NE_)                                                                                             \
-  if (s->NE == NE_) {                                                                                          \
-    AQ_HIP(hipFuncSetAttribute((const void *)aq_trait_wave_kernel<NE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((aq_trait_wave_kernel<NE_>), dim3(s->ntile), dim3(1024), lds, 0, t);                   \
+  t.ns = s->tw_ns;
+  size_t lds = (size_t)(s->tw_ns * s->n_pad + 8 * 256 + 32) * sizeof(double);
+#define AQ_TW(NE_, WPT_)                                                                                       \
+  if (s->NE == NE_ && s->WPT == WPT_) {                                                                        \
+    AQ_HIP(hipFuncSetAttribute((const void *)aq_trait_wave_kernel<NE_, WPT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((aq_trait_wave_kernel<NE_, WPT_>), dim3(s->ntile * WPT_), dim3(1024), lds, 0, t);     \
   } else
-  AQ_TW(4) AQ_TW(8) AQ_TW(16) AQ_TW(32) { return aq_fail(AQ_ERR_UNSUPPORTED, "no generic kernel instantiation for this n"); }
+  AQ_TW(4, 1) AQ_TW(8, 1) AQ_TW(16, 1) AQ_TW(32, 1)
+  AQ_TW(4, 2) AQ_TW(8, 2) AQ_TW(16, 2) AQ_TW(32, 2) AQ_TW(40, 2)
+  AQ_TW(4, 4) AQ_TW(8, 4) AQ_TW(16, 4) AQ_TW(32, 4) AQ_TW(40, 4)
+  { return aq_fail(AQ_ERR_UNSUPPORTED, "no generic kernel instantiation for this n"); }
 #undef AQ_TW
   AQ_HIP(hipGetLastError());
   return AQ_OK;
@@ -383,8 +389,8 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     if (!(pr->X[i] == pr->X[i])) return aq_fail(AQ_ERR_ARG, "X must be a non-empty a numeric matrix, finite without missing value.");
   bool has_missing = false;
   for (size_t i = 0; i < nq && !has_missing; i++) has_missing = !(pr->Y[i] == pr->Y[i]);
-  if (has_missing && pr->n > 2048)
-    return aq_fail(AQ_ERR_UNSUPPORTED, "missing values in Y with n > 2048 are not handled by the device path yet");
+  if (pr->n > 10240)
+    return aq_fail(AQ_ERR_UNSUPPORTED, "n > 10240: a trait's residual no longer fits the registers of 4 waves (not implemented yet)");
 
   aq_vb *s = new aq_vb();
   s->device = pr->device;
@@ -398,17 +404,17 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   else if (pr->n <= 256) { s->NT = 4; s->NW = 4; }
   else if (pr->n <= 512) { s->NT = 8; s->NW = 4; }
   else if (pr->n <= 1024) { s->NT = 16; s->NW = 4; }
-  else if (pr->n <= 2048) { s->NT = 16; s->NW = 8; }
-  else {
-    delete s;
-    return aq_fail(AQ_ERR_UNSUPPORTED, "n > 2048: the register-resident residual does not fit (not implemented yet)");
-  }
+  else { s->NT = 16; s->NW = 8; }   // n <= 2048; larger n runs on the generic kernel below
   {
     // default: look-ahead kernel; AQ_KERNEL=1 selects the two-barrier MFMA kernel, AQ_KERNEL=2 the generic one
     const char *ek = getenv("AQ_KERNEL");
     if (has_missing || (ek && atoi(ek) == 2) || pr->n > 1056) {
+      // generic kernel geometry: n_pad = 64 * NE * WPT samples, WPT waves (and workgroups) per trait (tile)
       s->use_tw = true;
-      s->NE = pr->n <= 256 ? 4 : pr->n <= 512 ? 8 : pr->n <= 1024 ? 16 : 32;
+      s->WPT = pr->n <= 2048 ? 1 : pr->n <= 5120 ? 2 : 4;
+      if (const char *e = getenv("AQ_TW_WPT")) { int v = atoi(e); if ((v == 2 || v == 4) && v > s->WPT) s->WPT = v; }   // test hook
+      const int per_lane = (pr->n + 64 * s->WPT - 1) / (64 * s->WPT);
+      s->NE = per_lane <= 4 ? 4 : per_lane <= 8 ? 8 : per_lane <= 16 ? 16 : per_lane <= 32 ? 32 : 40;
     }
     bool want_la = !s->use_tw && !(ek && atoi(ek) == 1);
     if (want_la && pr->n <= 1024) {
@@ -449,7 +455,12 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     }
   }
   if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
-  if (s->use_tw) s->n_pad = 64 * s->NE;
+  if (s->use_tw) {
+    s->n_pad = 64 * s->NE * s->WPT;
+    // SNP columns staged in LDS at a time: ns * n_pad doubles next to 18 KB of block scalars, within 160 KB
+    s->tw_ns = 4;
+    while (s->tw_ns > 1 && (size_t)(s->tw_ns * s->n_pad + 8 * 256 + 32) * sizeof(double) > 150 * 1024) s->tw_ns /= 2;
+  }
   // trait tiles per workgroup: 1 (two workgroups per CU) unless that would need a second round of workgroups
   s->TT = 1;
   if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 3 ? 3 : 1;
@@ -509,7 +520,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   }
   if (s->ngroup > 1) AQ_HIPF(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   AQ_TRYF(aq_dalloc(&s->rowA, (size_t)s->ntile * s->p_pad));
-  AQ_TRYF(aq_dalloc(&s->rowGB, (size_t)s->ntile * s->p_pad));
+  AQ_TRYF(aq_dalloc(&s->rowGB, (size_t)s->ntile * s->WPT * s->p_pad));
   AQ_TRYF(aq_dalloc(&s->Aarr, (size_t)s->ntile * s->p_pad * 16));
   AQ_TRYF(aq_dalloc(&s->Barr, (size_t)s->ntile * s->p_pad * 16));
   if (pr->ext_reduce_main) { s->red = pr->ext_reduce_main; s->own_red = false; }
@@ -649,7 +660,7 @@ static int aq_sweep_part_a(aq_vb *s) {
   s->pre_done = false;
   hipLaunchKernelGGL(aq_k_qpre, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, qv, s->sc, s->c);
   AQ_TRY(aq_launch_core(s, 0, s->c));
-  hipLaunchKernelGGL(aq_k_reduce_rows, dim3((s->p_pad + 255) / 256), dim3(256), 0, 0, s->rowA, s->rowGB, s->red, s->ntile, s->p_pad);
+  hipLaunchKernelGGL(aq_k_reduce_rows, dim3((s->p_pad + 255) / 256), dim3(256), 0, 0, s->rowA, s->rowGB, s->red, s->ntile, s->p_pad, s->WPT);
   hipLaunchKernelGGL(aq_k_reduce_q_scalars, dim3(1), dim3(1024), 0, 0, qv, s->red + s->p_pad);
   AQ_HIP(hipGetLastError());
   return AQ_OK;

@@ -106,3 +106,38 @@ def test_generic_kernel_matches_oracle(shape, na, monkeypatch):
     np.testing.assert_allclose(got["mu_beta_vb"], ref["mu_beta_vb"], rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], atol=1e-9)
     np.testing.assert_allclose(got["tau_vb"], ref["tau_vb"], rtol=1e-8)
+
+
+def _check_against_oracle(prob, q):
+    import atlasqtl_amd as A
+    from oracle import atlasqtl_oracle as O
+    tr = []
+    ref = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, (1, 2, 10), 1, 0.1, 1000, prob["list_hyper"],
+                                        prob["list_init"], trace=tr, full_output=True)
+    got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, (1, 2, 10), 1, 0.1, 1000, 0, prob["list_hyper"],
+                                        prob["list_init"], full_output=True, debug=True)
+    assert got["it"] == ref["it"]
+    lref = np.array([r["lb"] for r in tr if r["lb"] is not None])
+    np.testing.assert_allclose(got["elbo_trace"][1], lref, rtol=1e-9)
+    np.testing.assert_allclose(got["mu_beta_vb"], ref["mu_beta_vb"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], atol=1e-9)
+    np.testing.assert_allclose(got["theta_vb"], ref["theta_vb"], rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("wpt", [2, 4])
+@pytest.mark.parametrize("shape,na", [((300, 130, 49), 0.0), ((200, 90, 33), 0.08)])
+def test_generic_kernel_split_traits_matches_oracle(shape, na, wpt, monkeypatch):
+    """Generic kernel with a trait's samples split over 2 / 4 waves (the n > 2048 geometry, forced at small n)."""
+    from tests.util import make_problem
+    monkeypatch.setenv("AQ_KERNEL", "2")
+    monkeypatch.setenv("AQ_TW_WPT", str(wpt))
+    n, p, q = shape
+    _check_against_oracle(make_problem(n, p, q, p_act=8, prob_assoc=0.3, na_frac=na), q)
+
+
+@pytest.mark.parametrize("shape,na", [((2500, 40, 20), 0.05), ((5000, 24, 17), 0.05), ((5200, 20, 9), 0.0)])
+def test_large_n_matches_oracle(shape, na):
+    """n beyond the register-resident MFMA kernels (C5 has n = 5000 and a missingness mask): 2 and 4 waves per trait."""
+    from tests.util import make_problem
+    n, p, q = shape
+    _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q)

@@ -56,6 +56,10 @@ if __name__ == "__main__":
         timing(1000, 5000, 1000, na_frac=0.05)
         timing(1000, 5000, 4096)
         timing(2000, 3000, 1024)
+    if what == "bign":   # generic kernel beyond n = 2048 (C5-like n, reduced p and q)
+        timing(1000, 4000, 4096, sweeps=2, na_frac=0.05)
+        timing(5000, 2000, 2512, sweeps=2, na_frac=0.05)
+        timing(5000, 2000, 2512, sweeps=2)
     if what == "c3":
         timing(1000, 50000, 10000, sweeps=3)
     if what == "mid":
