@@ -22,6 +22,9 @@
 #define AQ_LOG_SQRT_2PI 0.91893853320467274178032973640562
 #define AQ_INV_SQRT2 0.70710678118654752440084436210485
 #define AQ_EULER_GAMMA 0.57721566490153286060651209008240
+#define AQ_SQRT_2_OVER_PI 0.79788456080286535587989211986876
+#define AQ_INV_SQRT_2PI 0.39894228040143267793994605993438
+#include "aq_erfcx_coef.h"
 
 // log Phi(x).  x > 0: log1p(-erfc(x/sqrt2)/2); -37 < x <= 0: log(erfc(-x/sqrt2)/2)
 // (erfc keeps full relative accuracy in its tail until it underflows near 26.5);
@@ -35,20 +38,79 @@ AQ_HD double aq_log_ndtr(double x) {
   return -0.5 * x * x - log(-x) - AQ_LOG_SQRT_2PI + log(ser);
 }
 
-// log Phi(x) and log(1 - Phi(x)) = log Phi(-x) from ONE erfc: with e = erfc(|x|/sqrt2)/2 (the tail on the far
-// side of x), the near-side value is log1p(-e) and the far-side one log(e).  Same formulas as aq_log_ndtr.
-AQ_HD void aq_log_ndtr_pair(double x, double *lP, double *l1) {
-  double ax = fabs(x);
-  double near_, far_;
-  if (ax < 37.0) {
-    double e = 0.5 * erfc(ax * AQ_INV_SQRT2);
-    near_ = log1p(-e);
-    far_ = log(e);
-  } else {
-    near_ = aq_log_ndtr(ax);
-    far_ = aq_log_ndtr(-ax);
+// erfcx(z) = exp(z^2) erfc(z) for z >= 0: Chebyshev series in t = 4/(4+z) (coefficients from
+// tools/gen_erfcx_cheb.py, truncation 4e-18 relative), Clenshaw recurrence.  No exponential, no branch, no
+// underflow for any z -- which is why the pre-pass is built on it rather than on erfc.
+AQ_HD double aq_erfcx_pos(double z) {
+  const double c[AQ_ERFCX_NCOEF] = {AQ_ERFCX_COEFS};
+  const double t = 4.0 / (4.0 + z);
+  const double x2 = 4.0 * t - 2.0;   // 2 (2t - 1)
+  double b1 = 0.0, b2 = 0.0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int j = AQ_ERFCX_NCOEF - 1; j >= 1; j--) {
+    double b0 = fma(x2, b1, c[j] - b2);
+    b2 = b1;
+    b1 = b0;
   }
-  if (x > 0.0) { *lP = near_; *l1 = far_; } else { *lP = far_; *l1 = near_; }
+  return t * fma(0.5 * x2, b1, c[0] - b2);
+}
+
+// Everything the probit link needs at one point x, from ONE erfcx, ONE exp, ONE log and ONE log1p:
+//   lP = log Phi(x), l1 = log(1 - Phi(x))                     pnorm(x, log.p = TRUE), lower / upper tail
+//   imr1 = phi(x)/Phi(x), imr0 = -phi(x)/(1 - Phi(x))         inv_mills_ratio_, R/utils.R:172-191 (with its clamps)
+// With w = erfcx(|x|/sqrt2) and E = exp(-x^2/2): the far tail is e = w E / 2, so
+//   log e = log(w/2) - x^2/2 (no cancellation, no underflow),  log(1 - e) = log1p(-e),
+//   phi/e = sqrt(2/pi)/w,  phi/(1 - e) = E / (sqrt(2 pi) (1 - e)).
+AQ_HD void aq_probit_terms(double x, double *lP, double *l1, double *imr1, double *imr0) {
+  const double w = aq_erfcx_pos(fabs(x) * AQ_INV_SQRT2);
+  const double hx2 = 0.5 * x * x;
+  const double hx2_lo = 0.5 * fma(x, x, -(x * x));     // x^2/2 = hx2 + hx2_lo exactly: keeps E good to an ulp at |x| ~ 37
+  const double E = exp(-hx2) * (1.0 - hx2_lo);
+  const double e = 0.5 * w * E;
+  const double far_ = log(0.5 * w) - hx2;
+  const double near_ = log1p(-e);
+  const double rf = AQ_SQRT_2_OVER_PI / w;
+  const double rn = (AQ_INV_SQRT_2PI * E) / (1.0 - e);
+  double i1, i0;
+  if (x > 0.0) { *lP = near_; *l1 = far_; i1 = rn; i0 = -rf; }
+  else { *lP = far_; *l1 = near_; i1 = rf; i0 = -rn; }
+  if (i1 < -x) i1 = -x;     // R/utils.R:180-181
+  if (i0 > -x) i0 = -x;     // R/utils.R:188-189
+  *imr1 = i1;
+  *imr0 = i0;
+}
+
+// The pre-pass form of the same quantities with one log fewer and two divisions fewer:
+//   A = log(1 - Phi(x)) - log Phi(x) = +-(log(w / (2 (1 - e))) - x^2/2),  the Mills ratios, and the far tail e
+// (log(1 - e) = log1p(-e) recovers the individual tails where the ELBO needs them: near = log1p(-e), far = near -+ A).
+AQ_HD void aq_probit_A_imr(double x, double *A, double *imr1, double *imr0, double *e_out) {
+  const double w = aq_erfcx_pos(fabs(x) * AQ_INV_SQRT2);
+  const double hx2 = 0.5 * x * x;
+  const double hx2_lo = 0.5 * fma(x, x, -(x * x));
+  const double E = exp(-hx2) * (1.0 - hx2_lo);
+  const double e = 0.5 * w * E;
+  const double om = 1.0 - e;
+  const double r = 1.0 / (w * om);
+  const double inv_w = r * om, inv_om = r * w;
+  const double rf = AQ_SQRT_2_OVER_PI * inv_w;
+  const double rn = (AQ_INV_SQRT_2PI * E) * inv_om;
+  const double Apos = log(0.5 * w * inv_om) - hx2;     // log(e / (1 - e))
+  double i1, i0;
+  if (x > 0.0) { *A = Apos; i1 = rn; i0 = -rf; }
+  else { *A = -Apos; i1 = rf; i0 = -rn; }
+  if (i1 < -x) i1 = -x;
+  if (i0 > -x) i0 = -x;
+  *imr1 = i1;
+  *imr0 = i0;
+  *e_out = e;
+}
+
+// log Phi(x) and log(1 - Phi(x)) = log Phi(-x) together.
+AQ_HD void aq_log_ndtr_pair(double x, double *lP, double *l1) {
+  double i1, i0;
+  aq_probit_terms(x, lP, l1, &i1, &i0);
 }
 
 // exp(-log(1+exp(x))) evaluated as the reference's logOnePlusExp does its case

@@ -170,25 +170,22 @@ __global__ __launch_bounds__(256) void aq_k_prepass(AqPrepass v) {
     double A = 0.0, B = 0.0, aa = 0.0;
     if (j < v.p && kvalid) {
       double u = v.theta[j] + zk;
-      double lP, l1;
-      aq_log_ndtr_pair(u, &lP, &l1);
-      A = l1 - lP;
-      double U = u, lPc = lP, l1c = l1, sc = 1.0;
-      if (!v.c_is_one) {
-        sc = v.sqrt_c;
-        U = sc * u;
-        aq_log_ndtr_pair(U, &lPc, &l1c);
+      double imr1, imr0, e;
+      aq_probit_A_imr(u, &A, &imr1, &imr0, &e);
+      if (!v.c_is_one) {   // annealed: the Mills ratios are taken at sqrt(c) u, R/update_vb.R:223-224
+        double Ac, ec;
+        aq_probit_A_imr(v.sqrt_c * u, &Ac, &imr1, &imr0, &ec);
+        imr1 /= v.sqrt_c;
+        imr0 /= v.sqrt_c;
       }
-      double base = -0.5 * U * U - AQ_LOG_SQRT_2PI;
-      double imr1 = exp(base - lPc);
-      if (imr1 < -U) imr1 = -U;
-      double imr0 = -exp(base - l1c);
-      if (imr0 > -U) imr0 = -U;
-      aa = u + imr0 / sc;
-      B = (imr1 - imr0) / sc;
+      aa = u + imr0;
+      B = imr1 - imr0;
       colA += aa;
       if (v.do_H) {
         double g = v.gam[off];
+        double near_ = log1p(-e);                   // log of the near-side probability; A = l1 - lP
+        double lP = u > 0.0 ? near_ : near_ - A;    // u <= 0: lP is the far tail = near - (near - far)
+        double l1 = u > 0.0 ? near_ + A : near_;
         hacc += g * lP + (1 - g) * l1 - g * log(g + eps) - (1 - g) * log(1 - g + eps);
       }
     }

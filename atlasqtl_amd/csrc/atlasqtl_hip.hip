@@ -1029,6 +1029,12 @@ extern "C" int aq_special_eval(int32_t which, const double *x, const double *x2,
       case 4: out[i] = aq_sigmoid_neg(x[i]); break;
       case 5: { double a_, b_; aq_log_ndtr_pair(x[i], &a_, &b_); out[i] = a_; } break;
       case 6: { double a_, b_; aq_log_ndtr_pair(x[i], &a_, &b_); out[i] = b_; } break;
+      case 7: { double a_, b_, c_, d_; aq_probit_terms(x[i], &a_, &b_, &c_, &d_); out[i] = c_; } break;
+      case 8: { double a_, b_, c_, d_; aq_probit_terms(x[i], &a_, &b_, &c_, &d_); out[i] = d_; } break;
+      case 9: out[i] = aq_erfcx_pos(x[i]); break;
+      case 10: { double a_, c_, d_, e_; aq_probit_A_imr(x[i], &a_, &c_, &d_, &e_); out[i] = a_; } break;
+      case 11: { double a_, c_, d_, e_; aq_probit_A_imr(x[i], &a_, &c_, &d_, &e_); out[i] = c_; } break;
+      case 12: { double a_, c_, d_, e_; aq_probit_A_imr(x[i], &a_, &c_, &d_, &e_); out[i] = d_; } break;
       default: return aq_fail(AQ_ERR_ARG, "aq_special_eval: unknown function id");
     }
   }

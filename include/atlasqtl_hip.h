@@ -167,7 +167,9 @@ int aq_vb_get_result(aq_vb_handle h, double *beta_vb, double *gam_vb, double *mu
 /* ------------------------------------------------------------------------------------------
  * Test hooks for the fp64 special functions the path uses (host evaluation of the same
  * header the kernels compile): which = 0 log_ndtr, 1 digamma, 2 expint_E1 (x<=1),
- * 3 gamma_inc_upper(a=x2, x), 4 sigmoid_neg, 5 / 6 log Phi / log(1-Phi) from the one-erfc pair.
+ * 3 gamma_inc_upper(a=x2, x), 4 sigmoid_neg, 5 / 6 log Phi / log(1-Phi) and 7 / 8 the inverse Mills
+ * ratios phi/Phi, -phi/(1-Phi) (R/utils.R:172-191) from aq_probit_terms, 9 erfcx(x), x >= 0,
+ * 10 / 11 / 12 log(1-Phi) - log Phi and the two Mills ratios from the pre-pass form aq_probit_A_imr.
  * Evaluates elementwise into out.
  * ---------------------------------------------------------------------------------------- */
 int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len);

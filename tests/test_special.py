@@ -25,12 +25,50 @@ def test_log_ndtr_both_tails():
     assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)) < 5e-14
 
 
-def test_log_ndtr_pair_one_erfc():
-    x = np.concatenate([np.linspace(-60, 60, 4001), [-37.0, 37.0, 0.0, 1e-300, -1e-300]])
-    for which, ref in ((5, sp.log_ndtr(x)), (6, sp.log_ndtr(-x))):
-        got = ev(which, x)
-        # (erfc's far tail, where log Phi ~ -1e-262, is good to ~6e-14 relative in glibc)
-        assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)) < 2e-13
+def _mp_log_ndtr(v):
+    import mpmath as mp
+    mp.mp.dps = 60
+    v = mp.mpf(float(v))
+    if v > 0:
+        return mp.log1p(-mp.erfc(v / mp.sqrt(2)) / 2)
+    return mp.log(mp.erfc(-v / mp.sqrt(2)) / 2)
+
+
+def test_probit_terms_against_mpmath():
+    """aq_probit_terms (one erfcx, one exp, one log, one log1p): both log tails and both inverse Mills ratios
+    (pnorm(log.p = TRUE) and inv_mills_ratio_, R/utils.R:172-191) against 60-digit mpmath; SciPy's own log_ndtr is
+    only good to 2e-13 in the far tails, so it is not the yardstick here."""
+    import mpmath as mp
+    x = np.concatenate([np.linspace(-40, 40, 801), np.linspace(-60, 60, 121), [-37.0, 37.0, 0.0, 1e-300, -1e-300, 100.0]])
+    ref = np.array([float(_mp_log_ndtr(v)) for v in x])
+    relerr = lambda got, want: np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300))
+    assert relerr(ev(5, x), ref) < 4e-15
+    assert relerr(ev(6, -x), ref) < 4e-15
+    assert relerr(ev(5, x), sp.log_ndtr(x)) < 5e-13
+    mp.mp.dps = 60
+    phi = lambda v: mp.exp(-mp.mpf(float(v)) ** 2 / 2) / mp.sqrt(2 * mp.pi)
+    imr1 = np.array([float(phi(v) / (mp.erfc(-mp.mpf(float(v)) / mp.sqrt(2)) / 2)) for v in x])
+    imr0 = np.array([float(-phi(v) / (mp.erfc(mp.mpf(float(v)) / mp.sqrt(2)) / 2)) for v in x])
+    assert relerr(ev(7, x), imr1) < 4e-15
+    assert relerr(ev(8, x), imr0) < 4e-15
+    # the pre-pass form (one log, one reciprocal): A = log(1-Phi) - log Phi carries an absolute error of a few ulp of 1
+    A_ref = np.array([float(_mp_log_ndtr(-v) - _mp_log_ndtr(v)) for v in x])
+    assert np.max(np.abs(ev(10, x) - A_ref) / np.maximum(np.abs(A_ref), 1.0)) < 4e-15
+    assert relerr(ev(11, x), imr1) < 6e-15
+    assert relerr(ev(12, x), imr0) < 6e-15
+    z = np.concatenate([np.linspace(0, 30, 301), [1e-300, 1e3, 1e8]])
+    mp.mp.dps = 60
+
+    def erfcx(v):
+        v = mp.mpf(float(v))
+        if v < 25:
+            return mp.exp(v * v) * mp.erfc(v)
+        s, term = mp.mpf(1), mp.mpf(1)
+        for m in range(1, 40):
+            term *= -(2 * m - 1) / (2 * v * v)
+            s += term
+        return s / (v * mp.sqrt(mp.pi))
+    assert relerr(ev(9, z), np.array([float(erfcx(v)) for v in z])) < 2e-15
 
 
 def test_digamma():
