@@ -297,7 +297,8 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbo
                    maxit=maxit, tol=tol, lb_opt=st["lb_opt"], diff_lb=st["diff_lb"])
         if full_output:
             res.update(sig02_inv_vb=st["sig02_inv_vb"], sig2_inv_vb=st["sig2_inv_vb"], elbo_trace=(its, lbs),
-                       core_ms=st["core_ms"], core_launches=st["core_launches"], lentz_iters=st["lentz_iters"])
+                       core_ms=st["core_ms"], core_launches=st["core_launches"], lentz_iters=st["lentz_iters"],
+                       core_kernel=st["core_kernel"])
         return res
     finally:
         run.close()

@@ -1,0 +1,362 @@
+// aq_core_sweep_mis.h -- the blocked f64-MFMA sweep for Y with missing values
+// (reference coreDualMisLoop, src/coreLoop.cpp:91-138, called from R/atlasqtl_global_local_core.R:172).
+//
+// With mis_pat (n x q, 1 = observed) the reference's Gram matrix becomes trait specific, cp_X - cp_X_rm[[k]]
+// (R/atlasqtl_global_local_core.R:27-31).  In n-space that is a masked residual
+//     R_ik = mis_ik (y_ik - sum_j x_ij beta_jk)
+// and the blocked Gauss-Seidel of aq_core_sweep.h carries over with two changes:
+//   * S = X_b' R_K is unchanged (R is already masked); the update becomes R_K -= mis .* (X_b delta): the MFMA
+//     result is re-masked in registers (the mask of a wave's residual tiles is 4 NT bits per lane);
+//   * the in-block coupling uses the trait's own Gram block
+//         G_b^(k) = X_b' diag(mis_k) X_b = X_b'X_b - Xm_k' Xm_k,      Xm_k = the rows of X_b at trait k's missing samples,
+//     a rank-m_k correction computed with the SAME f64 MFMA: for the 16x16x4 instruction the A operand (16 SNPs x 4
+//     samples) and the B operand (4 samples x 16 SNPs) of Xm_k'Xm_k are the same register -- lane l holds
+//     x[I_k[4t + (l>>4)]][l & 15], one gathered 128-byte row segment per 16 lanes.  Its diagonal is X_norm_sq(j,k)
+//     (R/atlasqtl_global_local_core.R:23), from which the p x q sig2_beta_vb (R/update_vb.R:45) follows per entry.
+//     The 16 corrections of block b+1 are computed by the six waves that would otherwise idle while wave 0 runs the
+//     sequential pass of block b.
+// Everything per (j,k) uses the same trait-tiled arrays and the same 6 column sums as aq_trait_wave.h (the generic
+// kernel, which stays the fallback for n > 2048 or more than AQ_MIS_MMAX missing samples in a trait).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "aq_special.h"
+#include "aq_core_sweep.h"
+#include "aq_vec_kernels.h"
+
+#define AQ_MIS_MMAX 512   // most missing samples of one trait the LDS index lists hold (rounded up to 4)
+
+struct AqMisArgs {
+  const double2 *XA, *XU;  // MFMA operand layouts of X (aq_core_sweep.h)
+  const double *G;         // [nb][16][16] X_b'X_b
+  const double *XR;        // [nb][NR][16] X_b row-major (sample, snp); rows >= n are zero, row n_pad is the padding target
+  double *R;               // [ntile][n_pad][16] masked residual
+  const double *mis;       // [ntile][n_pad][16] 1 = observed
+  double *gam, *mu;        // [ntile][p_pad][16]
+  const double *Aarr, *Barr;
+  const double *tau, *log_tau, *sig2b;   // [q_pad]; sig2b = initial sig2_beta_vb (init mode only)
+  const AqScalars *sc;     // sig2_inv, log_sig2_inv of this sweep
+  const int *midx;         // [ntile][16][Mmax] sample indices of the missing entries of each trait, padded with n_pad
+  const int *mcnt4;        // [ntile][16] number of 4-sample groups in each list
+  double *sums;            // [6][q_pad]: sum gam, sum m2, sum X_norm_sq (m2 - beta^2), sum gam*b, ||R||^2, sum gam*log sig2_beta
+  double *rowGB;           // [ntile][p_pad]
+  double c;
+  int p, q, p_pad, q_pad, n_pad, nb, ntile, dmode, mode, NR, Mmax;
+};
+
+// NT: 16-sample residual tiles per wave; 8 waves: n_pad = 128 NT.
+template <int NT>
+__global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisArgs a) {
+  constexpr int NW = 8, NTT = NT * NW;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int tile = blockIdx.x;
+  const bool helper = tid < 256;
+  const int hj = (tid >> 4) & 15, hk = tid & 15;
+
+  extern __shared__ double lds[];
+  double *Sp = lds;                       // [NW][256] per-wave partial S [snp][trait]
+  double *LcA = Sp + NW * 256;            // c (A - log(sig2_beta)/2 + cst)      src/coreLoop.cpp:127-129
+  double *Lm1 = LcA + 256, *LB = Lm1 + 256, *Lgam = LB + 256, *Lmu = Lgam + 256, *Ldel = Lmu + 256;
+  double *Lcoef = Ldel + 256;             // c sig2_beta tau                      :125
+  double *Lci2s = Lcoef + 256;            // c / (2 sig2_beta)
+  double *Ls2 = Lci2s + 256, *Lls2 = Ls2 + 256, *Lxn = Lls2 + 256;
+  double *Lred = Lxn + 256;               // [5][256] running column sums per helper thread
+  double *Lrn = Lred + 5 * 256;           // [NW*4][16]
+  double *LGk = Lrn + NW * 4 * 16;        // [2][256*17]: G_b^(k)[i][j] at (i*16 + j)*17 + k
+  int *Lidx = (int *)(LGk + 2 * 256 * 17);   // [16][Mmax]
+  int *Lcnt = Lidx + 16 * a.Mmax;            // [16]
+
+  // ---- residual tiles and their mask bits into registers ----
+  aq_d4 Rr[NT];
+  unsigned long long mb = 0;
+  {
+    const double *Rg = a.R + (size_t)tile * a.n_pad * 16;
+    const double *Mg = a.mis + (size_t)tile * a.n_pad * 16;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int s = 16 * (w * NT + t) + aq_drow(a.dmode, r, g);
+        Rr[t][r] = Rg[(size_t)s * 16 + col];
+        if (Mg[(size_t)s * 16 + col] != 0.0) mb |= 1ull << (4 * t + r);
+      }
+  }
+  auto remask = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) Rr[t][r] = ((mb >> (4 * t + r)) & 1ull) ? Rr[t][r] : 0.0;
+  };
+  for (int e = tid; e < 16 * a.Mmax; e += 512) Lidx[e] = a.midx[(size_t)tile * 16 * a.Mmax + e];
+  if (tid < 16) Lcnt[tid] = a.mcnt4[tile * 16 + tid];
+  if (helper)
+#pragma unroll
+    for (int v = 0; v < 5; v++) Lred[v * 256 + tid] = 0.0;
+
+  const double2 *XAw = a.XA + (size_t)(w * NT) * 128 + lane;   // + (b*NTT + t)*128 + h*64
+  const double2 *XUw = a.XU + (size_t)(w * NT) * 128 + lane;
+  const int kk_h = tile * 16 + hk;
+  const bool kvalid = kk_h < a.q;
+  const size_t tbase = (size_t)tile * a.p_pad * 16;
+  const double tau_h = a.tau[kk_h];
+  const double s2init_h = a.sig2b[kk_h];
+  const double cstna_h = -(a.log_tau[kk_h] + a.sc->log_sig2_inv) / 2;            // src/coreLoop.cpp:108
+  const double sig2_inv = a.sc->sig2_inv;
+  __syncthreads();
+
+  // G_bb^(k) for the 16 traits of the tile -> LGk[buf]; waves 1,2,3,5,6,7 (never on the recurrence wave's SIMD)
+  auto compute_gk = [&](int bb, int buf) {
+    if (w == 0 || w == 4) return;
+    const int slot = w < 4 ? w - 1 : w - 2;
+    const double *xr = a.XR + (size_t)bb * a.NR * 16 + col;
+    double gb[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) gb[r] = a.G[(size_t)bb * 256 + aq_drow(a.dmode, r, g) * 16 + col];
+    double *dst = LGk + buf * (256 * 17);
+    for (int k = slot; k < 16; k += 6) {
+      aq_d4 acc = (aq_d4){0, 0, 0, 0};
+      const int n4 = Lcnt[k];
+      const int *ix = Lidx + k * a.Mmax + g;
+#pragma unroll 4
+      for (int t = 0; t < n4; t++) {
+        double x = xr[(size_t)ix[4 * t] * 16];
+        acc = aq_mfma(x, x, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) dst[(aq_drow(a.dmode, r, g) * 16 + col) * 17 + k] = gb[r] - acc[r];
+    }
+  };
+
+  if (a.mode == 1) {
+    // ---------------- init: R = mis .* (Y - X (gam*mu)), initial column sums ----------------
+    for (int b = 0; b < a.nb; b++) {
+      compute_gk(b, 0);
+      double gm = 0.0, mu = 0.0;
+      if (helper) {
+        size_t off = tbase + (size_t)(16 * b) * 16 + tid;
+        gm = a.gam[off];
+        mu = a.mu[off];
+        Ldel[tid] = gm * mu;                                  // update_beta_vb_, R/update_vb.R:17
+      }
+      __syncthreads();
+      if (helper && kvalid && (16 * b + hj) < a.p) {
+        double xn = LGk[(hj * 16 + hj) * 17 + hk];            // X_norm_sq(j,k)
+        double be = gm * mu;
+        double m2 = (mu * mu + s2init_h) * gm;                // first m2_beta uses the initial q-vector sig2_beta_vb, :113
+        Lred[tid] += gm;
+        Lred[256 + tid] += m2;
+        Lred[512 + tid] += xn * (m2 - be * be);
+      }
+      double nd[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) nd[s] = -Ldel[(4 * s + g) * 16 + col];
+      const double2 *xu = XUw + (size_t)b * NTT * 128;
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        double2 u0 = xu[t * 128], u1 = xu[t * 128 + 64];
+        Rr[t] = aq_mfma(u0.x, nd[0], Rr[t]);
+        Rr[t] = aq_mfma(u0.y, nd[1], Rr[t]);
+        Rr[t] = aq_mfma(u1.x, nd[2], Rr[t]);
+        Rr[t] = aq_mfma(u1.y, nd[3], Rr[t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) remask(t);
+  } else {
+    // ---------------- full sweep ----------------
+    double st_A = 0, st_g = 0, st_m = 0, st_B = 0;
+    auto stage_load = [&](int b) {
+      size_t off = tbase + (size_t)(16 * b) * 16 + tid;
+      st_A = a.Aarr[off];
+      st_g = a.gam[off];
+      st_m = a.mu[off];
+      st_B = a.Barr[off];
+    };
+    auto stage_commit = [&](int buf) {
+      const double xn = LGk[buf * (256 * 17) + (hj * 16 + hj) * 17 + hk];
+      const double s2 = 1.0 / (a.c * (xn + sig2_inv) * tau_h);            // update_sig2_beta_vb_, R/update_vb.R:45
+      const double ls2 = log(s2);
+      LcA[tid] = a.c * (st_A - 0.5 * ls2 + cstna_h);
+      Lcoef[tid] = a.c * s2 * tau_h;
+      Lci2s[tid] = a.c * 0.5 / s2;
+      Ls2[tid] = s2;
+      Lls2[tid] = ls2;
+      Lxn[tid] = xn;
+      Lm1[tid] = st_g * st_m;
+      LB[tid] = st_B;
+    };
+    // prologue: S of block 0, G^(k) of block 0, staged scalars of block 0
+    aq_d4 acc = (aq_d4){0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      double2 a0 = XAw[t * 128], a1 = XAw[t * 128 + 64];
+      acc = aq_mfma(a0.x, Rr[t][0], acc);
+      acc = aq_mfma(a0.y, Rr[t][1], acc);
+      acc = aq_mfma(a1.x, Rr[t][2], acc);
+      acc = aq_mfma(a1.y, Rr[t][3], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    compute_gk(0, 0);
+    if (helper) stage_load(0);
+    __syncthreads();
+    if (helper) stage_commit(0);
+
+    for (int b = 0; b < a.nb; b++) {
+      const bool more = (b + 1 < a.nb);
+      const int buf = b & 1;
+      if (helper && more) stage_load(b + 1);
+#pragma unroll
+      for (int i = 0; i < 4; i++) Sp[w * 256 + aq_drow(a.dmode, i, g) * 16 + col] = acc[i];
+      aq_lds_barrier();
+
+      if (w == 0) {
+        // ---- sequential pass over the 16 SNPs, lane = trait (src/coreLoop.cpp:115-133) ----
+        if (lane < 16) {
+          const double *Gk = LGk + buf * (256 * 17) + col;
+          double S[16];
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            double s = Sp[j * 16 + col];
+#pragma unroll
+            for (int ww = 1; ww < NW; ww++) s += Sp[ww * 256 + j * 16 + col];
+            S[j] = s;
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);   // bound the LDS loads in flight (VGPR budget)
+          }
+          double m1o = Lm1[col], cA = LcA[col], cf = Lcoef[col], ci = Lci2s[col], dj = Lxn[col];
+#pragma unroll 1
+          for (int j = 0; j < 16; j++) {
+            const int jn = ((j + 1) & 15) * 16 + col;
+            double m1o_n = Lm1[jn], cA_n = LcA[jn], cf_n = Lcoef[jn], ci_n = Lci2s[jn], d_n = Lxn[jn];
+            double s = S[0] + m1o * dj;                       // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1 (cp_X - cp_X_rm_k)(j,j))   :121
+            double mu = cf * s;                               // :125
+            double x = cA - (mu * mu) * ci;                   // :127-129
+            double gm = aq_sigmoid_neg(x);
+            double dl = gm * mu - m1o;                        // m1 - m1_old   :130
+            // in-block part of :132 with the trait's own Gram block; rows past the block are never consumed
+#pragma unroll
+            for (int i0 = 0; i0 < 15; i0 += 8) {
+              double gc[8];
+#pragma unroll
+              for (int i = 0; i < 8; i++) {
+                int row = j + 1 + i0 + i;
+                row = row < 15 ? row : 15;
+                gc[i] = (i0 + i < 15) ? Gk[(row * 16 + j) * 17] : 0.0;
+              }
+#pragma unroll
+              for (int i = 0; i < 8; i++)
+                if (i0 + i < 15) S[i0 + i] = S[i0 + i + 1] - gc[i] * dl;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            Lgam[j * 16 + col] = gm;
+            Lmu[j * 16 + col] = mu;
+            Ldel[j * 16 + col] = dl;
+            m1o = m1o_n; cA = cA_n; cf = cf_n; ci = ci_n; dj = d_n;
+          }
+        }
+      } else if (more) {
+        compute_gk(b + 1, buf ^ 1);
+      }
+      aq_lds_barrier();
+
+      // ---- finalize block b (helper threads): stores and column/row sums ----
+      if (helper) {
+        const int j = 16 * b + hj;
+        double gm = Lgam[tid], mu = Lmu[tid];
+        size_t off = tbase + (size_t)(16 * b) * 16 + tid;
+        double gbv = 0.0;
+        a.gam[off] = gm;
+        a.mu[off] = mu;
+        if (kvalid && j < a.p) {
+          double be = gm * mu;
+          double m2 = (mu * mu + Ls2[tid]) * gm;              // update_m2_beta_, R/update_vb.R:19-31
+          gbv = gm * LB[tid];
+          Lred[tid] += gm;
+          Lred[256 + tid] += m2;
+          Lred[512 + tid] += Lxn[tid] * (m2 - be * be);       // kappa's X_norm_sq terms, R/update_vb.R:152-154
+          Lred[768 + tid] += gbv;
+          Lred[1024 + tid] += gm * Lls2[tid];
+        }
+        gbv += __shfl_xor(gbv, 8, 64);
+        gbv += __shfl_xor(gbv, 4, 64);
+        gbv += __shfl_xor(gbv, 2, 64);
+        gbv += __shfl_xor(gbv, 1, 64);
+        if (hk == 0) a.rowGB[(size_t)tile * a.p_pad + j] = gbv;
+      }
+
+      // ---- R -= mis .* (X_b delta), and S of block b+1, tile by tile ----
+      double nd[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) nd[s] = -Ldel[(4 * s + g) * 16 + col];
+      acc = (aq_d4){0, 0, 0, 0};
+      const double2 *xu = XUw + (size_t)b * NTT * 128;
+      const double2 *xa = XAw + (size_t)(more ? b + 1 : b) * NTT * 128;
+      double2 cu0 = xu[0], cu1 = xu[64], ca0 = xa[0], ca1 = xa[64];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        double2 nu0, nu1, na0, na1;
+        if (t + 1 < NT) {
+          nu0 = xu[(t + 1) * 128]; nu1 = xu[(t + 1) * 128 + 64];
+          na0 = xa[(t + 1) * 128]; na1 = xa[(t + 1) * 128 + 64];
+        }
+        Rr[t] = aq_mfma(cu0.x, nd[0], Rr[t]);
+        Rr[t] = aq_mfma(cu0.y, nd[1], Rr[t]);
+        Rr[t] = aq_mfma(cu1.x, nd[2], Rr[t]);
+        Rr[t] = aq_mfma(cu1.y, nd[3], Rr[t]);
+        remask(t);
+        acc = aq_mfma(ca0.x, Rr[t][0], acc);
+        acc = aq_mfma(ca0.y, Rr[t][1], acc);
+        acc = aq_mfma(ca1.x, Rr[t][2], acc);
+        acc = aq_mfma(ca1.y, Rr[t][3], acc);
+        if (t + 1 < NT) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (helper && more) stage_commit(buf ^ 1);
+    }
+  }
+
+  // ---- residual back, ||R_k||^2, column sums ----
+  __syncthreads();
+  {
+    double *Rg = a.R + (size_t)tile * a.n_pad * 16;
+    double rn = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int s = 16 * (w * NT + t) + aq_drow(a.dmode, r, g);
+        double v = Rr[t][r];
+        Rg[(size_t)s * 16 + col] = v;
+        rn += v * v;
+      }
+    Lrn[(w * 4 + g) * 16 + col] = rn;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int kk = tile * 16 + tid;
+    const size_t Q = a.q_pad;
+    double r2 = 0.0;
+#pragma unroll 1
+    for (int s = 0; s < NW * 4; s++) r2 += Lrn[s * 16 + tid];
+    a.sums[4 * Q + kk] = r2;
+#pragma unroll 1
+    for (int u = 0; u < 5; u++) {   // Lred rows: gam, m2, sx, gam*b, gam*log sig2_beta -> sums rows 0,1,2,3,5
+      double acc2 = 0.0;
+#pragma unroll 1
+      for (int jj = 0; jj < 16; jj++) acc2 += Lred[u * 256 + jj * 16 + tid];
+      a.sums[(size_t)(u < 4 ? u : 5) * Q + kk] = acc2;
+    }
+  }
+}
+
+// X_b in row-major panels for the gathers: XR[(b*NR + i)*16 + jj] = x_{i, 16 b + jj} (0 beyond n or p)
+__global__ void aq_k_build_xr(const double *__restrict__ X, double *__restrict__ XR, int n, int p, int nb, int NR) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)nb * NR * 16;
+  if (e >= total) return;
+  int jj = (int)(e & 15);
+  size_t rest = e >> 4;
+  int i = (int)(rest % NR);
+  int b = (int)(rest / NR);
+  int j = 16 * b + jj;
+  XR[e] = (i < n && j < p) ? X[(size_t)i + (size_t)n * j] : 0.0;
+}

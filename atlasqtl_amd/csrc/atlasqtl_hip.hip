@@ -18,6 +18,7 @@
 #include "aq_gram_loop.h"
 #include "aq_special.h"
 #include "aq_trait_wave.h"
+#include "aq_core_sweep_mis.h"
 #include "aq_vec_kernels.h"
 
 // ------------------------------------------------------------------ errors ----
@@ -139,6 +140,10 @@ struct aq_vb {
   int NE = 0;            // samples per lane of the generic kernel
   int WPT = 1;           // generic kernel: waves (and workgroups) sharing one trait (tile); also rowGB rows per tile
   int tw_ns = 4;         // generic kernel: SNP columns staged in LDS at a time
+  bool use_mis = false;  // masked blocked MFMA kernel (aq_core_sweep_mis.h): missing Y, n <= 2048
+  double *XR = nullptr;  // [nb][NR][16] row-major SNP panels (gather source of the per-trait Gram corrections)
+  int *midx = nullptr, *mcnt4 = nullptr;   // per-trait lists of missing samples
+  int Mmax = 0, NR = 0;
   double *Xcm = nullptr, *mis = nullptr, *XN = nullptr;
   int ncu = 256;
   int nseg = 1, ngroup = 1; // SNP segments x trait-tile groups (streams) of the full-sweep launches
@@ -175,7 +180,7 @@ struct aq_vb {
 static void aq_free_all(aq_vb *s) {
   if (!s) return;
   hipSetDevice(s->device);
-  void *ptrs[] = {s->Xcm, s->mis, s->XN, s->XA, s->XU, s->G, s->Gx, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
+  void *ptrs[] = {s->XR, s->midx, s->mcnt4, s->Xcm, s->mis, s->XN, s->XA, s->XU, s->G, s->Gx, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
                   s->eta_h, s->kappa_h, s->n0, s->nobs, s->zeta, s->tau, s->sig2b, s->log_tau, s->eta_vb, s->kappa_vb,
                   s->coef, s->inv2s, s->cst, s->sums, s->rowA, s->rowGB, s->Aarr, s->Barr, s->colApart, s->Hpart, s->sc};
   for (void *ptr : ptrs)
@@ -239,6 +244,25 @@ static int aq_launch_tw(aq_vb *s, int mode, double c) {
   return AQ_OK;
 }
 
+static int aq_launch_mis(aq_vb *s, int mode, double c) {
+  AqMisArgs t;
+  t.XA = s->XA; t.XU = s->XU; t.G = s->G; t.XR = s->XR; t.R = s->R; t.mis = s->mis; t.gam = s->gam; t.mu = s->mu;
+  t.Aarr = s->Aarr; t.Barr = s->Barr; t.tau = s->tau; t.log_tau = s->log_tau; t.sig2b = s->sig2b; t.sc = s->sc;
+  t.midx = s->midx; t.mcnt4 = s->mcnt4; t.sums = s->sums; t.rowGB = s->rowGB; t.c = c;
+  t.p = s->p; t.q = s->q; t.p_pad = s->p_pad; t.q_pad = s->q_pad; t.n_pad = s->n_pad; t.nb = s->nb; t.ntile = s->ntile;
+  t.dmode = s->dmode; t.mode = mode; t.NR = s->NR; t.Mmax = s->Mmax;
+  size_t lds = (size_t)(8 * 256 + 11 * 256 + 5 * 256 + 8 * 4 * 16 + 2 * 256 * 17) * sizeof(double) + (size_t)(16 * s->Mmax + 16) * sizeof(int);
+#define AQ_MIS(NT_)                                                                                             \
+  if (s->NT == NT_) {                                                                                          \
+    AQ_HIP(hipFuncSetAttribute((const void *)aq_core_sweep_mis_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((aq_core_sweep_mis_kernel<NT_>), dim3(s->ntile), dim3(512), lds, 0, t);                \
+  } else
+  AQ_MIS(1) AQ_MIS(2) AQ_MIS(4) AQ_MIS(8) AQ_MIS(16) { return aq_fail(AQ_ERR_UNSUPPORTED, "no masked MFMA kernel instantiation for this n"); }
+#undef AQ_MIS
+  AQ_HIP(hipGetLastError());
+  return AQ_OK;
+}
+
 static int aq_launch_core(aq_vb *s, int mode, double c) {
   AqCoreArgs a;
   a.XA = s->XA; a.XU = s->XU; a.G = s->G; a.Gx = s->Gx; a.R = s->R; a.gam = s->gam; a.mu = s->mu;
@@ -252,7 +276,9 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   AQ_HIP(hipEventCreate(&e0));
   AQ_HIP(hipEventCreate(&e1));
   AQ_HIP(hipEventRecord(e0, 0));
-  if (s->use_tw) {
+  if (s->use_mis) {
+    AQ_TRY(aq_launch_mis(s, mode, c));
+  } else if (s->use_tw) {
     AQ_TRY(aq_launch_tw(s, mode, c));
   } else if (s->use_la) {
     dim3 blockl(8 * 64);
@@ -408,7 +434,23 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   {
     // default: look-ahead kernel; AQ_KERNEL=1 selects the two-barrier MFMA kernel, AQ_KERNEL=2 the generic one
     const char *ek = getenv("AQ_KERNEL");
-    if (has_missing || (ek && atoi(ek) == 2) || pr->n > 1056) {
+    // missing values: masked blocked MFMA kernel while n fits 8 waves x 16 residual tiles and no trait misses more
+    // than AQ_MIS_MMAX samples; otherwise (and with AQ_KERNEL=2) the generic kernel
+    int max_missing = 0;
+    if (has_missing) {
+      for (int k = 0; k < pr->q; k++) {
+        int m = 0;
+        for (int i = 0; i < pr->n; i++) m += !(pr->Y[(size_t)i + (size_t)pr->n * k] == pr->Y[(size_t)i + (size_t)pr->n * k]);
+        if (m > max_missing) max_missing = m;
+      }
+    }
+    if (has_missing && pr->n <= 2048 && max_missing <= AQ_MIS_MMAX && !(ek && atoi(ek) == 2)) {
+      s->use_mis = true;
+      s->NW = 8;
+      s->NT = pr->n <= 128 ? 1 : pr->n <= 256 ? 2 : pr->n <= 512 ? 4 : pr->n <= 1024 ? 8 : 16;
+      s->Mmax = (max_missing + 3) / 4 * 4;
+      if (s->Mmax < 4) s->Mmax = 4;
+    } else if (has_missing || (ek && atoi(ek) == 2) || pr->n > 1056) {
       // generic kernel geometry: n_pad = 64 * NE * WPT samples, WPT waves (and workgroups) per trait (tile)
       s->use_tw = true;
       s->WPT = pr->n <= 2048 ? 1 : pr->n <= 5120 ? 2 : 4;
@@ -416,7 +458,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       const int per_lane = (pr->n + 64 * s->WPT - 1) / (64 * s->WPT);
       s->NE = per_lane <= 4 ? 4 : per_lane <= 8 ? 8 : per_lane <= 16 ? 16 : per_lane <= 32 ? 32 : 40;
     }
-    bool want_la = !s->use_tw && !(ek && atoi(ek) == 1);
+    bool want_la = !s->use_tw && !s->use_mis && !(ek && atoi(ek) == 1);
     if (want_la && pr->n <= 1024) {
       // 6 matrix waves x NT residual tiles each (n padded to 96 NT samples) + the recurrence wave
       s->use_la = true;
@@ -455,6 +497,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     }
   }
   if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
+  if (s->use_mis) s->NR = s->n_pad + 8;
   if (s->use_tw) {
     s->n_pad = 64 * s->NE * s->WPT;
     // SNP columns staged in LDS at a time: ns * n_pad doubles next to 18 KB of block scalars, within 160 KB
@@ -465,7 +508,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   s->TT = 1;
   if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 3 ? 3 : 1;
   else if (s->NW == 4 && s->ntile > 512) s->TT = 3;
-  if (s->NW != 4 || s->use_la) s->TT = 1;
+  if (s->NW != 4 || s->use_la || s->use_mis) s->TT = 1;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, pr->device) == hipSuccess && prop.multiProcessorCount > 0) s->ncu = prop.multiProcessorCount;
@@ -495,6 +538,23 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   if (s->use_tw) {
     AQ_TRYF(aq_dalloc(&s->mis, (size_t)s->ntile * s->n_pad * 16));
     AQ_TRYF(aq_dalloc(&s->XN, (size_t)s->ntile * s->p_pad * 16));
+  }
+  if (s->use_mis) {
+    AQ_TRYF(aq_dalloc(&s->mis, (size_t)s->ntile * s->n_pad * 16));
+    AQ_TRYF(aq_dalloc(&s->XR, (size_t)s->nb * s->NR * 16));
+    AQ_TRYF(aq_dalloc(&s->midx, (size_t)s->ntile * 16 * s->Mmax));
+    AQ_TRYF(aq_dalloc(&s->mcnt4, (size_t)s->ntile * 16));
+    // lists of missing samples per trait, padded to groups of 4 with the all-zero row n_pad of XR
+    std::vector<int> idx((size_t)s->ntile * 16 * s->Mmax, s->n_pad), cnt((size_t)s->ntile * 16, 0);
+    for (int k = 0; k < s->q; k++) {
+      int m = 0;
+      int *dst = idx.data() + (size_t)k * s->Mmax;      // trait k = tile (k / 16), slot (k % 16): contiguous
+      for (int i = 0; i < s->n; i++)
+        if (!(pr->Y[(size_t)i + (size_t)s->n * k] == pr->Y[(size_t)i + (size_t)s->n * k])) dst[m++] = i;
+      cnt[k] = (m + 3) / 4;
+    }
+    AQ_HIPF(hipMemcpy(s->midx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    AQ_HIPF(hipMemcpy(s->mcnt4, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   AQ_TRYF(aq_dalloc(&s->R, (size_t)s->ntile * s->n_pad * 16));
   AQ_TRYF(aq_dalloc(&s->gam, (size_t)s->ntile * s->p_pad * 16));
@@ -544,6 +604,10 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       hipLaunchKernelGGL(aq_k_build_x_layouts, dim3((unsigned)((xelems + 255) / 256)), dim3(256), 0, 0, Xd, s->XA, s->XU,
                          s->n, s->p, s->nb, NTT, s->dmode);
       hipLaunchKernelGGL(aq_k_gram_blocks, dim3(s->nb), dim3(256), 0, 0, Xd, s->G, s->Gx, s->n, s->p);
+      if (s->use_mis) {
+        size_t tot = (size_t)s->nb * s->NR * 16;
+        hipLaunchKernelGGL(aq_k_build_xr, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, Xd, s->XR, s->n, s->p, s->nb, s->NR);
+      }
       AQ_HIPF(hipDeviceSynchronize());
       AQ_HIPF(hipFree(Xd));
     }
@@ -556,7 +620,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->n_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->R,
                        s->n, s->q, s->n_pad, 1);
     AQ_HIPF(hipDeviceSynchronize());
-    if (s->use_tw) {   // mis_pat <- ifelse(is.na(Y), 0, 1), R/atlasqtl_global_local_core.R:21
+    if (s->use_tw || s->use_mis) {   // mis_pat <- ifelse(is.na(Y), 0, 1), R/atlasqtl_global_local_core.R:21
       std::vector<double> mk(nq);
       for (size_t i = 0; i < nq; i++) mk[i] = (pr->Y[i] == pr->Y[i]) ? 1.0 : 0.0;
       AQ_HIPF(hipMemcpy(stage, mk.data(), nq * sizeof(double), hipMemcpyHostToDevice));
@@ -865,6 +929,7 @@ extern "C" int aq_vb_get_status(aq_vb_handle s, aq_vb_status *st) {
   st->sig02_inv_vb = h.sig02_inv;
   st->sig2_inv_vb = h.sig2_inv;
   st->lentz_iters = h.lentz_iters;
+  st->core_kernel = s->use_mis ? 3 : s->use_tw ? 2 : s->use_la ? 0 : 1;
   return AQ_OK;
 }
 

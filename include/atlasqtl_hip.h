@@ -152,6 +152,8 @@ typedef struct aq_vb_status {
   int32_t core_launches;
   double sig02_inv_vb, sig2_inv_vb;
   int32_t lentz_iters;   /* shared Lentz iteration count of the last non-annealed sweep */
+  int32_t core_kernel;   /* which core sweep kernel this handle runs: 0 look-ahead MFMA, 1 two-barrier MFMA,
+                            2 generic wave-per-trait (VALU), 3 masked MFMA (missing values in Y) */
 } aq_vb_status;
 int aq_vb_get_status(aq_vb_handle h, aq_vb_status *st);
 

@@ -108,7 +108,7 @@ def test_generic_kernel_matches_oracle(shape, na, monkeypatch):
     np.testing.assert_allclose(got["tau_vb"], ref["tau_vb"], rtol=1e-8)
 
 
-def _check_against_oracle(prob, q):
+def _check_against_oracle(prob, q, kernel=None):
     import atlasqtl_amd as A
     from oracle import atlasqtl_oracle as O
     tr = []
@@ -116,12 +116,15 @@ def _check_against_oracle(prob, q):
                                         prob["list_init"], trace=tr, full_output=True)
     got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, (1, 2, 10), 1, 0.1, 1000, 0, prob["list_hyper"],
                                         prob["list_init"], full_output=True, debug=True)
+    if kernel is not None:
+        assert got["core_kernel"] == kernel
     assert got["it"] == ref["it"]
     lref = np.array([r["lb"] for r in tr if r["lb"] is not None])
     np.testing.assert_allclose(got["elbo_trace"][1], lref, rtol=1e-9)
     np.testing.assert_allclose(got["mu_beta_vb"], ref["mu_beta_vb"], rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], atol=1e-9)
     np.testing.assert_allclose(got["theta_vb"], ref["theta_vb"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(got["tau_vb"], ref["tau_vb"], rtol=1e-8)
 
 
 @pytest.mark.parametrize("wpt", [2, 4])
@@ -141,3 +144,21 @@ def test_large_n_matches_oracle(shape, na):
     from tests.util import make_problem
     n, p, q = shape
     _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q)
+
+
+@pytest.mark.parametrize("shape,na", [((70, 17, 1), 0.1), ((128, 40, 16), 0.3), ((200, 90, 33), 0.08), ((300, 130, 49), 0.02),
+                                      ((600, 50, 20), 0.05), ((1100, 40, 18), 0.05), ((2048, 33, 17), 0.03)])
+def test_masked_mfma_kernel_matches_oracle(shape, na):
+    """Missing values in Y on the blocked f64-MFMA kernel (aq_core_sweep_mis.h, core_kernel == 3): every residual-tile
+    geometry NT = 1, 2, 4, 8, 16, ragged p and q, one trait, 30 % missing."""
+    from tests.util import make_problem
+    n, p, q = shape
+    _check_against_oracle(make_problem(n, p, q, p_act=min(6, p // 3), prob_assoc=1.0 if q <= 20 else 0.3, na_frac=na), q, kernel=3)
+
+
+def test_missing_beyond_index_list_capacity_falls_back_to_generic():
+    """More than AQ_MIS_MMAX = 512 missing samples in a trait: the generic kernel takes over (core_kernel == 2)."""
+    from tests.util import make_problem
+    prob = make_problem(1500, 24, 5, p_act=4, prob_assoc=1.0, na_frac=0.4)
+    assert np.isnan(prob["Y"]).sum(axis=0).max() > 512
+    _check_against_oracle(prob, 5, kernel=2)

@@ -56,6 +56,11 @@ if __name__ == "__main__":
         timing(1000, 5000, 1000, na_frac=0.05)
         timing(1000, 5000, 4096)
         timing(2000, 3000, 1024)
+    if what == "mis":   # masked MFMA kernel vs generic kernel, same data
+        parity(200, 90, 33) if False else None
+        timing(1000, 4000, 4096, sweeps=2, na_frac=0.05)
+        timing(500, 4000, 4096, sweeps=2, na_frac=0.05)
+        timing(2000, 2000, 4096, sweeps=2, na_frac=0.05)
     if what == "bign":   # generic kernel beyond n = 2048 (C5-like n, reduced p and q)
         timing(1000, 4000, 4096, sweeps=2, na_frac=0.05)
         timing(5000, 2000, 2512, sweeps=2, na_frac=0.05)
