@@ -66,6 +66,7 @@ SYMBOLS = {
     "aq_vb_get_elbo_trace": (C.c_int32, [C.c_void_p, ip, dp, C.c_int32]),
     "aq_vb_get_result": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
     "aq_special_eval": (C.c_int, [C.c_int32, dp, dp, dp, C.c_int64]),
+    "aq_special_eval_device": (C.c_int, [C.c_int32, dp, dp, dp, C.c_int64, C.c_int32]),
     "aq_q_approx_vec": (C.c_int, [dp, dp, C.c_int64, ip]),
 }
 

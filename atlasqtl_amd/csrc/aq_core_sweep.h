@@ -278,6 +278,7 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
         const double rc_coef = a.coef[kk];
         const double rc_cinv2s = a.c * a.inv2s[kk];
         const double rc_cst = a.cst[kk];
+        const double rc_K = rc_coef * rc_coef * rc_cinv2s;
         // S[0] is always the SNP being visited: after each step the vector shifts down by one
         // while the in-block Gram correction is applied (rows past the block read the zero pad).
         double S[16];
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
           double m1o_n = Lm1[rt][jn * 16 + col], cA_n = a.c * (LA[rt][jn * 16 + col] + rc_cst), d_n = LG[jn * 33];
           double s = S[0] + m1o * dj;                       // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1*cp_X(j,j))   :71
           double mu = rc_coef * s;                          // :73
-          double x = cA - (mu * mu) * rc_cinv2s;            // c*(log(1-Phi) - log Phi - mu^2/(2 sig2) + cst)   :75-77
-          double gm = aq_sigmoid_neg(x);
+          double x = fma(-(s * s), rc_K, cA);               // c*(log(1-Phi) - log Phi - mu^2/(2 sig2) + cst), mu^2 = coef^2 s^2   :75-77
+          double gm = aq_sigmoid_neg_fast(x);
           double dl = gm * mu - m1o;                        // m1 - m1_old, m1 = gam*mu   :79
           // in-block part of :81: S shifts down by one; G[j+1+i][j] (symmetric) reads the zero pad past the block
 #pragma unroll

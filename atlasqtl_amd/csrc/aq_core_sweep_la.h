@@ -106,6 +106,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const double rc_coef = a.coef[kk];
       const double rc_cinv2s = a.c * a.inv2s[kk];
       const double rc_cst = a.cst[kk];
+      const double rc_K = rc_coef * rc_coef * rc_cinv2s;   // keeps mu off the dependency chain of the recursion
       aq_lds_barrier();   // prologue
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           double m1o_n = Lm1[par][jn * 16 + col], cA_n = a.c * (LA[par][jn * 16 + col] + rc_cst), d_n = LG[par][jn * 33];
           double s = S[0] + m1o * dj;                       // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1*cp_X(j,j))   :71
           double mu = rc_coef * s;                          // :73
-          double x = cA - (mu * mu) * rc_cinv2s;            // c*(log(1-Phi) - log Phi - mu^2/(2 sig2) + cst)   :75-77
+          double x = fma(-(s * s), rc_K, cA);               // c*(log(1-Phi) - log Phi - mu^2/(2 sig2) + cst), mu^2 = coef^2 s^2   :75-77
           // cross-block correction of the NEXT SNP (row j+1 sits in S[1]); independent of the chain
           {
             double cx = 0.0;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
             for (int i = 0; i < 16; i++) cx += LGx[par][jn * 16 + i] * dlp[i];
             if (j < 15) S[1] -= cx;
           }
-          double gm = aq_sigmoid_neg(x);
+          double gm = aq_sigmoid_neg_fast(x);
           double dl = gm * mu - m1o;                        // m1 - m1_old, m1 = gam*mu   :79
           // in-block part of :81: S shifts down by one; G[j+1+i][j] reads the zero pad past the block
 #pragma unroll

@@ -36,7 +36,7 @@ struct AqMisArgs {
   const double *tau, *log_tau, *sig2b;   // [q_pad]; sig2b = initial sig2_beta_vb (init mode only)
   const AqScalars *sc;     // sig2_inv, log_sig2_inv of this sweep
   const int *midx;         // [ntile][16][Mmax] sample indices of the missing entries of each trait, padded with n_pad
-  const int *mcnt4;        // [ntile][16] number of 4-sample groups in each list
+  const int *mcnt4;        // [ntile][16] number of 4-sample groups in each list (a multiple of 4: lists are padded to 16 samples)
   double *sums;            // [6][q_pad]: sum gam, sum m2, sum X_norm_sq (m2 - beta^2), sum gam*b, ||R||^2, sum gam*log sig2_beta
   double *rowGB;           // [ntile][p_pad]
   double c;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
   double *LcA = Sp + NW * 256;            // c (A - log(sig2_beta)/2 + cst)      src/coreLoop.cpp:127-129
   double *Lm1 = LcA + 256, *LB = Lm1 + 256, *Lgam = LB + 256, *Lmu = Lgam + 256, *Ldel = Lmu + 256;
   double *Lcoef = Ldel + 256;             // c sig2_beta tau                      :125
-  double *Lci2s = Lcoef + 256;            // c / (2 sig2_beta)
+  double *Lci2s = Lcoef + 256;            // K = coef^2 c / (2 sig2_beta)
   double *Ls2 = Lci2s + 256, *Lls2 = Ls2 + 256, *Lxn = Lls2 + 256;
   double *Lred = Lxn + 256;               // [5][256] running column sums per helper thread
   double *Lrn = Lred + 5 * 256;           // [NW*4][16]
@@ -115,10 +115,13 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
       aq_d4 acc = (aq_d4){0, 0, 0, 0};
       const int n4 = Lcnt[k];
       const int *ix = Lidx + k * a.Mmax + g;
-#pragma unroll 4
-      for (int t = 0; t < n4; t++) {
-        double x = xr[(size_t)ix[4 * t] * 16];
-        acc = aq_mfma(x, x, acc);
+      for (int t = 0; t < n4; t += 4) {   // lists are padded to whole groups of 16 samples: 4 gathers in flight per step
+        const int i0 = ix[4 * t], i1 = ix[4 * t + 4], i2 = ix[4 * t + 8], i3 = ix[4 * t + 12];
+        const double x0 = xr[(size_t)i0 * 16], x1 = xr[(size_t)i1 * 16], x2 = xr[(size_t)i2 * 16], x3 = xr[(size_t)i3 * 16];
+        acc = aq_mfma(x0, x0, acc);
+        acc = aq_mfma(x1, x1, acc);
+        acc = aq_mfma(x2, x2, acc);
+        acc = aq_mfma(x3, x3, acc);
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) dst[(aq_drow(a.dmode, r, g) * 16 + col) * 17 + k] = gb[r] - acc[r];
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
       const double ls2 = log(s2);
       LcA[tid] = a.c * (st_A - 0.5 * ls2 + cstna_h);
       Lcoef[tid] = a.c * s2 * tau_h;
-      Lci2s[tid] = a.c * 0.5 / s2;
+      Lci2s[tid] = (a.c * s2 * tau_h) * (a.c * s2 * tau_h) * (a.c * 0.5 / s2);   // coef^2 c/(2 sig2_beta): x = cA - s^2 K
       Ls2[tid] = s2;
       Lls2[tid] = ls2;
       Lxn[tid] = xn;
@@ -229,8 +232,8 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
             double m1o_n = Lm1[jn], cA_n = LcA[jn], cf_n = Lcoef[jn], ci_n = Lci2s[jn], d_n = Lxn[jn];
             double s = S[0] + m1o * dj;                       // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1 (cp_X - cp_X_rm_k)(j,j))   :121
             double mu = cf * s;                               // :125
-            double x = cA - (mu * mu) * ci;                   // :127-129
-            double gm = aq_sigmoid_neg(x);
+            double x = fma(-(s * s), ci, cA);                 // :127-129 with mu^2 = coef^2 s^2 (keeps mu off the chain)
+            double gm = aq_sigmoid_neg_fast(x);
             double dl = gm * mu - m1o;                        // m1 - m1_old   :130
             // in-block part of :132 with the trait's own Gram block; rows past the block are never consumed
 #pragma unroll

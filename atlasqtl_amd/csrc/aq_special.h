@@ -121,6 +121,45 @@ AQ_HD double aq_sigmoid_neg(double x) {
   return num / (1.0 + e);
 }
 
+// The same function with a short dependency chain, for the sequential SNP recursion where every dependent fp64
+// operation costs ~10 ns per SNP and trait tile: exp(-|x|) by a two-step Cody-Waite reduction and a degree-12
+// Taylor polynomial in Estrin form (depth 4 instead of 11), the reciprocal of 1 + e in [1, 2] by v_rcp_f64 and two
+// Newton steps (no div_scale / div_fixup needed in that range).  21 dependent operations per SNP instead of 36;
+// relative error <= 3e-16 (tests/test_special.py).
+AQ_HD double aq_exp_neg_fast(double ax) {   // exp(-ax) for ax >= 0
+  ax = fmin(ax, 800.0);                     // exp(-800) = 0 in fp64; keeps the reduction finite for any input
+  const double k = rint(ax * -1.44269504088896340736);
+  double r = fma(k, -6.93147180369123816490e-01, -ax);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  const double r2 = r * r;
+  const double p01 = 1.0 + r;
+  const double p23 = fma(r, 1.0 / 6.0, 0.5);
+  const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  const double p67 = fma(r, 1.0 / 5040.0, 1.0 / 720.0);
+  const double p89 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0);
+  const double pAB = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0);
+  const double r4 = r2 * r2;
+  const double q0 = fma(p23, r2, p01);
+  const double q1 = fma(p67, r2, p45);
+  const double q2 = fma(pAB, r2, p89);
+  const double r8 = r4 * r4;
+  const double s0 = fma(q1, r4, q0);
+  const double s1 = fma(1.0 / 479001600.0, r4, q2);
+  return ldexp(fma(s1, r8, s0), (int)k);
+}
+AQ_HD double aq_sigmoid_neg_fast(double x) {
+  const double e = aq_exp_neg_fast(fabs(x));
+  const double d = 1.0 + e;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+#else
+  const double y = 1.0 / d;
+#endif
+  return ((x < 0.0) ? 1.0 : e) * y;
+}
+
 // digamma for x > 0: upward recurrence to x >= 10, then the asymptotic series.
 AQ_HD double aq_digamma(double x) {
   if (!(x > 0.0)) return NAN;          // the path only calls it with positive arguments; never loop on garbage

@@ -448,8 +448,8 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       s->use_mis = true;
       s->NW = 8;
       s->NT = pr->n <= 128 ? 1 : pr->n <= 256 ? 2 : pr->n <= 512 ? 4 : pr->n <= 1024 ? 8 : 16;
-      s->Mmax = (max_missing + 3) / 4 * 4;
-      if (s->Mmax < 4) s->Mmax = 4;
+      s->Mmax = (max_missing + 15) / 16 * 16;
+      if (s->Mmax < 16) s->Mmax = 16;
     } else if (has_missing || (ek && atoi(ek) == 2) || pr->n > 1056) {
       // generic kernel geometry: n_pad = 64 * NE * WPT samples, WPT waves (and workgroups) per trait (tile)
       s->use_tw = true;
@@ -544,14 +544,14 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     AQ_TRYF(aq_dalloc(&s->XR, (size_t)s->nb * s->NR * 16));
     AQ_TRYF(aq_dalloc(&s->midx, (size_t)s->ntile * 16 * s->Mmax));
     AQ_TRYF(aq_dalloc(&s->mcnt4, (size_t)s->ntile * 16));
-    // lists of missing samples per trait, padded to groups of 4 with the all-zero row n_pad of XR
+    // lists of missing samples per trait, padded to groups of 16 with the all-zero row n_pad of XR
     std::vector<int> idx((size_t)s->ntile * 16 * s->Mmax, s->n_pad), cnt((size_t)s->ntile * 16, 0);
     for (int k = 0; k < s->q; k++) {
       int m = 0;
       int *dst = idx.data() + (size_t)k * s->Mmax;      // trait k = tile (k / 16), slot (k % 16): contiguous
       for (int i = 0; i < s->n; i++)
         if (!(pr->Y[(size_t)i + (size_t)s->n * k] == pr->Y[(size_t)i + (size_t)s->n * k])) dst[m++] = i;
-      cnt[k] = (m + 3) / 4;
+      cnt[k] = (m + 15) / 16 * 4;
     }
     AQ_HIPF(hipMemcpy(s->midx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     AQ_HIPF(hipMemcpy(s->mcnt4, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1080,29 +1080,60 @@ extern "C" int aq_core_dual_mis_loop(const double *cp_X, const double *const *cp
 }
 
 // ------------------------------------------------------------- test hooks ----
+// one element of the test hook, compiled for host and device from the same header the kernels use
+__host__ __device__ static inline bool aq_special_one(int which, double x, double x2, double *out) {
+  double a_, b_, c_, d_;
+  switch (which) {
+    case 0: *out = aq_log_ndtr(x); return true;
+    case 1: *out = aq_digamma(x); return true;
+    case 2: *out = aq_expint_e1_small(x); return true;
+    case 3: *out = aq_gamma_inc_upper(x2, x); return true;
+    case 4: *out = aq_sigmoid_neg(x); return true;
+    case 5: aq_log_ndtr_pair(x, &a_, &b_); *out = a_; return true;
+    case 6: aq_log_ndtr_pair(x, &a_, &b_); *out = b_; return true;
+    case 7: aq_probit_terms(x, &a_, &b_, &c_, &d_); *out = c_; return true;
+    case 8: aq_probit_terms(x, &a_, &b_, &c_, &d_); *out = d_; return true;
+    case 9: *out = aq_erfcx_pos(x); return true;
+    case 10: aq_probit_A_imr(x, &a_, &b_, &c_, &d_); *out = a_; return true;
+    case 11: aq_probit_A_imr(x, &a_, &b_, &c_, &d_); *out = b_; return true;
+    case 12: aq_probit_A_imr(x, &a_, &b_, &c_, &d_); *out = c_; return true;
+    case 13: *out = aq_sigmoid_neg_fast(x); return true;
+    default: return false;
+  }
+}
+
 extern "C" int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len) {
   if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval: bad argument");
-  for (int64_t i = 0; i < len; i++) {
-    switch (which) {
-      case 0: out[i] = aq_log_ndtr(x[i]); break;
-      case 1: out[i] = aq_digamma(x[i]); break;
-      case 2: out[i] = aq_expint_e1_small(x[i]); break;
-      case 3:
-        if (!x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
-        out[i] = aq_gamma_inc_upper(x2[i], x[i]);
-        break;
-      case 4: out[i] = aq_sigmoid_neg(x[i]); break;
-      case 5: { double a_, b_; aq_log_ndtr_pair(x[i], &a_, &b_); out[i] = a_; } break;
-      case 6: { double a_, b_; aq_log_ndtr_pair(x[i], &a_, &b_); out[i] = b_; } break;
-      case 7: { double a_, b_, c_, d_; aq_probit_terms(x[i], &a_, &b_, &c_, &d_); out[i] = c_; } break;
-      case 8: { double a_, b_, c_, d_; aq_probit_terms(x[i], &a_, &b_, &c_, &d_); out[i] = d_; } break;
-      case 9: out[i] = aq_erfcx_pos(x[i]); break;
-      case 10: { double a_, c_, d_, e_; aq_probit_A_imr(x[i], &a_, &c_, &d_, &e_); out[i] = a_; } break;
-      case 11: { double a_, c_, d_, e_; aq_probit_A_imr(x[i], &a_, &c_, &d_, &e_); out[i] = c_; } break;
-      case 12: { double a_, c_, d_, e_; aq_probit_A_imr(x[i], &a_, &c_, &d_, &e_); out[i] = d_; } break;
-      default: return aq_fail(AQ_ERR_ARG, "aq_special_eval: unknown function id");
-    }
+  if (which == 3 && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
+  for (int64_t i = 0; i < len; i++)
+    if (!aq_special_one(which, x[i], x2 ? x2[i] : 0.0, &out[i])) return aq_fail(AQ_ERR_ARG, "aq_special_eval: unknown function id");
+  return AQ_OK;
+}
+
+__global__ void aq_k_special_eval(int which, const double *x, const double *x2, double *out, long long len) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) aq_special_one(which, x[i], x2 ? x2[i] : 0.0, &out[i]);
+}
+
+extern "C" int aq_special_eval_device(int32_t which, const double *x, const double *x2, double *out, int64_t len, int32_t device) {
+  if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: bad argument");
+  if (which < 0 || which > 13) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: unknown function id");
+  if (which == 3 && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: x2 required");
+  AQ_TRY(aq_need_device(device));
+  if (len == 0) return AQ_OK;
+  double *dx = nullptr, *dx2 = nullptr, *dout = nullptr;
+  AQ_HIP(hipMalloc((void **)&dx, len * sizeof(double)));
+  AQ_HIP(hipMalloc((void **)&dout, len * sizeof(double)));
+  AQ_HIP(hipMemcpy(dx, x, len * sizeof(double), hipMemcpyHostToDevice));
+  if (x2) {
+    AQ_HIP(hipMalloc((void **)&dx2, len * sizeof(double)));
+    AQ_HIP(hipMemcpy(dx2, x2, len * sizeof(double), hipMemcpyHostToDevice));
   }
+  hipLaunchKernelGGL(aq_k_special_eval, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, 0, which, dx, dx2, dout, (long long)len);
+  hipError_t e = hipMemcpy(out, dout, len * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(dx); hipFree(dout);
+  if (dx2) hipFree(dx2);
+  if (e != hipSuccess) return aq_fail(AQ_ERR_DEVICE, std::string("aq_special_eval_device: ") + hipGetErrorString(e));
   return AQ_OK;
 }
 

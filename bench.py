@@ -158,8 +158,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("AQ_BENCH_FORCE_PG") == "1":   # the env switch rehearses the RCCL path on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD
 
@@ -216,7 +217,8 @@ def main():
             "config": {"workload": f"atlasqtl VB sweep (S1-S22 incl. scheduled ELBO), n={n} p={p} q={q}, "
                                    f"anneal=(1,2,10) on, horseshoe global-local, sweeps {st0['it'] + 1}-{st1['it']}",
                        "n": n, "p": p, "q": q, "q_per_gpu": q_loc, "parallelism": f"trait-sharded x{world}",
-                       "elbo_evals_in_timed_region": st1["n_elbo"] - st0["n_elbo"], "setup_s": round(t_setup, 1)},
+                       "elbo_evals_in_timed_region": st1["n_elbo"] - st0["n_elbo"], "elbo_last": st1["lb_opt"],
+                       "setup_s": round(t_setup, 1)},
             "roofline": {"bound": "mfma", "kernel": "aq_core_sweep_la_kernel", "achieved": achieved,
                          "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,
                          "traffic": PMC_TRAFFIC_C3_BYTES if (n, p, q, world) == (1000, 50000, 10000, 1) else None,

@@ -172,9 +172,12 @@ int aq_vb_get_result(aq_vb_handle h, double *beta_vb, double *gam_vb, double *mu
  * 3 gamma_inc_upper(a=x2, x), 4 sigmoid_neg, 5 / 6 log Phi / log(1-Phi) and 7 / 8 the inverse Mills
  * ratios phi/Phi, -phi/(1-Phi) (R/utils.R:172-191) from aq_probit_terms, 9 erfcx(x), x >= 0,
  * 10 / 11 / 12 log(1-Phi) - log Phi and the two Mills ratios from the pre-pass form aq_probit_A_imr.
- * Evaluates elementwise into out.
+ * 13 the short-dependency-chain sigmoid of the SNP recursion (aq_sigmoid_neg_fast).
+ * Evaluates elementwise into out.  aq_special_eval_device runs the same switch in a kernel on `device`
+ * (host pointers in and out): the device build of these functions (ocml, v_rcp_f64) is what the sweep executes.
  * ---------------------------------------------------------------------------------------- */
 int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len);
+int aq_special_eval_device(int32_t which, const double *x, const double *x2, double *out, int64_t len, int32_t device);
 /* exp(x) E1(x) for a vector with the reference's shared Lentz stopping rule (R/utils.R:380-423);
  * host evaluation; writes the shared iteration count to *iters. */
 int aq_q_approx_vec(const double *x, double *out, int64_t len, int32_t *iters);

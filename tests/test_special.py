@@ -104,6 +104,18 @@ def test_sigmoid_matches_reference_form():
     assert np.max(np.abs(got[ok] - ref[ok]) / ref[ok]) < 1e-13
 
 
+def test_short_chain_sigmoid():
+    """aq_sigmoid_neg_fast (Estrin exp + reciprocal in [1,2]) against the reference form exp(-log(1+exp(x))),
+    src/coreLoop.cpp:28-33,75-77, in 60-digit arithmetic."""
+    import mpmath as mp
+    mp.mp.dps = 60
+    x = np.concatenate([np.linspace(-800, 800, 1601), np.linspace(-40, 40, 4001), [0.0, 1e-300, -1e-300, 1e4, -1e4, 744.9, 745.5]])
+    ref = np.array([float(1 / (1 + mp.exp(mp.mpf(float(v))))) for v in x])
+    got = ev(13, x)
+    assert np.max(np.abs(got - ref) / np.maximum(ref, 1e-300)) < 4e-16 * 4
+    assert np.max(np.abs(ev(4, x) - ref) / np.maximum(ref, 1e-300)) < 4e-16 * 4
+
+
 def test_q_approx_vec_shared_stopping_rule():
     """exp(x) E1(x) with the reference's SHARED Lentz iteration count (R/utils.R:380-423, note N2)."""
     L = _lib.lib()
