@@ -100,38 +100,71 @@ def build_problem(n, p, q_total, k0, k1, device, seed=123):
     return np.asfortranarray(X), np.asfortranarray(Y[:, sl]), lh_loc, li_loc
 
 
-def cpu_baseline(n, p, q_total, seed=7, budget_s=12.0):
-    """The oracle's n-space port of src/coreLoop.cpp:38-86 (oracle/core_loop_oracle.c, gcc -O2,
-    one thread) timed on a trait sub-sample at full n and p, scaled by q/q_sub (traits are
-    independent and equal-cost).  Covers step S9 only, i.e. it flatters the CPU."""
+def cpu_baseline(n, p, q_total, seed=7, budget_s=10.0):
+    """CPU figures for step S9 (the core loop) on the GPU box's host cores, all from the oracle's C restatement
+    (oracle/core_loop_oracle.c, gcc -O2 -ffp-contract=off):
+      value      n-space port of src/coreLoop.cpp:38-86, ONE thread (the reference is single-threaded, src/Makevars),
+                 on a trait sub-sample at full n and p, scaled by q/q_sub (traits are independent and equal-cost);
+      all_cores  the same port with the traits spread over every host core (threads; ctypes releases the GIL);
+      gram_space the reference's own formulation (p-long AXPY on X'X per (SNP, trait), :58-84), one thread, at a reduced
+                 p_sub where X'X fits comfortably, scaled by (p/p_sub)^2 q/q_sub -- an extrapolation, labelled as such.
+    Covers S9 only, i.e. it flatters the CPU (the R-side p x q passes come on top)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import atlasqtl_oracle as O
     rng = np.random.default_rng(seed)
     X = np.asfortranarray(rng.normal(size=(n, p)))
-    q_sub = 4
 
-    def once(qs):
+    def state(pp, qs):
+        gam = np.asfortranarray(rng.uniform(0.001, 0.01, size=(pp, qs)))
+        mu = np.asfortranarray(rng.normal(size=(pp, qs)) * 0.01)
+        return (gam, mu, np.asfortranarray(gam * mu), np.asfortranarray(np.full((pp, qs), -6.0)),
+                np.asfortranarray(np.full((pp, qs), -0.0025)))
+
+    def nspace(qs, threads=1):
         R = np.asfortranarray(rng.normal(size=(n, qs)))
-        gam = np.asfortranarray(rng.uniform(0.001, 0.01, size=(p, qs)))
-        mu = np.asfortranarray(rng.normal(size=(p, qs)) * 0.01)
-        m1 = np.asfortranarray(gam * mu)
-        lP = np.asfortranarray(np.full((p, qs), -6.0))
-        l1 = np.asfortranarray(np.full((p, qs), -0.0025))
+        gam, mu, m1, lP, l1 = state(p, qs)
+        args = (X, R, None, np.full(p, n - 1.0), gam, lP, l1, -0.3, np.zeros(qs), m1, mu, np.full(qs, 1e-3), np.ones(qs), 1.0)
         t0 = time.perf_counter()
-        O.nspace_loop(X, R, None, np.full(p, n - 1.0), gam, lP, l1, -0.3, np.zeros(qs), m1, mu, np.full(qs, 1e-3),
-                      np.ones(qs), 1.0)
+        if threads == 1:
+            O.nspace_loop(*args)
+        else:
+            cuts = [qs * i // threads for i in range(threads + 1)]
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(lambda i: O.nspace_loop(*args, k_begin=cuts[i], k_end=cuts[i + 1]), range(threads)))
         return time.perf_counter() - t0
 
-    t = once(q_sub)
+    q_sub = 4
+    t = nspace(q_sub)
     per_trait = t / q_sub
     extra = int(max(0, min(4096, (budget_s - t) / max(per_trait, 1e-9))))
     if extra >= 4:
-        t2 = once(extra)
+        t2 = nspace(extra)
         per_trait = (t + t2) / (q_sub + extra)
         q_sub += extra
-    sweep_s = per_trait * q_total
-    return {"value": 1.0 / sweep_s, "unit": "sweeps/s", "cores": 1, "kind": "port",
-            "sample": f"oracle n-space core loop (step S9 only), {q_sub} of {q_total} traits at full n={n}, p={p}, "
-                      f"{per_trait * q_sub:.1f} s measured, scaled by q/q_sub"}
+    out = {"value": 1.0 / (per_trait * q_total), "unit": "sweeps/s", "cores": 1, "kind": "port",
+           "sample": f"oracle n-space core loop (step S9 only), {q_sub} of {q_total} traits at full n={n}, p={p}, "
+                     f"{per_trait * q_sub:.1f} s measured, scaled by q/q_sub"}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if cores > 1:
+        qs = max(cores, min(4096, int(cores * 6.0 / max(per_trait, 1e-9))))     # ~6 s of wall-clock
+        qs -= qs % cores
+        tm = nspace(qs, cores)
+        out["all_cores"] = {"value": 1.0 / (tm / qs * q_total), "unit": "sweeps/s", "cores": cores,
+                            "sample": f"same port, {qs} traits over {cores} threads, {tm:.1f} s"}
+    p_sub, qg = min(p, 4000), 8
+    Xs = X[:, :p_sub]
+    cp_X = np.asfortranarray(Xs.T @ Xs)
+    gam, mu, m1, lP, l1 = state(p_sub, qg)
+    cp_Y_X = np.asfortranarray(rng.normal(size=(qg, p_sub)))
+    cpb = np.asfortranarray(cp_X @ m1)
+    t0 = time.perf_counter()
+    O.core_dual_loop(cp_X, cp_Y_X, gam, lP, l1, -0.3, np.zeros(qg), m1, cpb, mu, np.full(qg, 1e-3), np.ones(qg),
+                     np.arange(p_sub, dtype=np.int32), np.arange(qg, dtype=np.int32), 1.0)
+    tg = time.perf_counter() - t0
+    out["gram_space"] = {"value": 1.0 / (tg * (p / p_sub) ** 2 * q_total / qg), "unit": "sweeps/s", "cores": 1,
+                         "sample": f"the reference's formulation (src/coreLoop.cpp:58-84 restated), p_sub={p_sub}, {qg} traits, "
+                                   f"{tg:.2f} s, EXTRAPOLATED by (p/p_sub)^2 q/q_sub (X'X at full p would need {8e-9 * p * p:.0f} GB)"}
+    return out
 
 
 def main():
