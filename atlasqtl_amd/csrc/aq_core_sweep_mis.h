@@ -15,15 +15,20 @@
 //     (R/atlasqtl_global_local_core.R:23), from which the p x q sig2_beta_vb (R/update_vb.R:45) follows per entry.
 //     The 16 corrections of block b+1 are computed by the six waves that would otherwise idle while wave 0 runs the
 //     sequential pass of block b.
+// n beyond one workgroup's registers (8 waves x 16 tiles = 2048 samples): C workgroups share a trait tile, each
+// holds n_pad/C samples.  Per SNP block every one of them publishes its 16x16 partial S (agent-scope atomic stores,
+// then a flag), waits for the C-1 others (bounded spin), adds the partials in the same fixed order and runs the SAME sequential pass
+// redundantly -- so delta is bitwise identical in all of them and no second exchange is needed.  Workgroups of a
+// tile are adjacent in dispatch order, hence a waiting one always has its partners resident or next to be dispatched.
 // Everything per (j,k) uses the same trait-tiled arrays and the same 6 column sums as aq_trait_wave.h (the generic
-// kernel, which stays the fallback for n > 2048 or more than AQ_MIS_MMAX missing samples in a trait).
+// kernel, which stays the fallback for more than AQ_MIS_MMAX missing samples in a trait and for n > 16384).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "aq_special.h"
 #include "aq_core_sweep.h"
 #include "aq_vec_kernels.h"
 
-#define AQ_MIS_MMAX 512   // most missing samples of one trait the LDS index lists hold (rounded up to 4)
+#define AQ_MIS_MMAX 1024  // most missing samples of one trait the LDS index lists hold (16-bit indices, padded to 16)
 
 struct AqMisArgs {
   const double2 *XA, *XU;  // MFMA operand layouts of X (aq_core_sweep.h)
@@ -41,15 +46,23 @@ struct AqMisArgs {
   double *rowGB;           // [ntile][p_pad]
   double c;
   int p, q, p_pad, q_pad, n_pad, nb, ntile, dmode, mode, NR, Mmax;
+  int C;                   // workgroups per trait tile (sample split); block tile*C + part
+  double *Pbuf;            // [ntile][2][C][256] partial S of each part, double-buffered by block parity
+  int *pflag;              // [ntile][C] number of blocks whose partial S this part has published
+  int *errflag;            // set when a bounded wait expires
+  double *rnpart;          // [C][q_pad] partial ||R_k||^2 of each part (C > 1)
 };
 
-// NT: 16-sample residual tiles per wave; 8 waves: n_pad = 128 NT.
+// NT: 16-sample residual tiles per wave; 8 waves, C parts: n_pad = 128 NT C.
 template <int NT>
 __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisArgs a) {
-  constexpr int NW = 8, NTT = NT * NW;
+  constexpr int NW = 8;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, col = lane & 15;
-  const int tile = blockIdx.x;
+  const int tile = blockIdx.x / a.C, part = blockIdx.x - tile * a.C;
+  const bool lead = (part == 0);          // the part that records the tile's results
+  const int NTT = NT * NW * a.C;          // residual tiles of the whole sample axis
+  const int wt0 = (part * NW + w) * NT;   // first residual tile of this wave
   const bool helper = tid < 256;
   const int hj = (tid >> 4) & 15, hk = tid & 15;
 
@@ -63,8 +76,8 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
   double *Lred = Lxn + 256;               // [5][256] running column sums per helper thread
   double *Lrn = Lred + 5 * 256;           // [NW*4][16]
   double *LGk = Lrn + NW * 4 * 16;        // [2][256*17]: G_b^(k)[i][j] at (i*16 + j)*17 + k
-  int *Lidx = (int *)(LGk + 2 * 256 * 17);   // [16][Mmax]
-  int *Lcnt = Lidx + 16 * a.Mmax;            // [16]
+  int *Lcnt = (int *)(LGk + 2 * 256 * 17);            // [16]
+  unsigned short *Lidx = (unsigned short *)(Lcnt + 16);   // [16][Mmax]
 
   // ---- residual tiles and their mask bits into registers ----
   aq_d4 Rr[NT];
@@ -76,7 +89,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
     for (int t = 0; t < NT; t++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        int s = 16 * (w * NT + t) + aq_drow(a.dmode, r, g);
+        int s = 16 * (wt0 + t) + aq_drow(a.dmode, r, g);
         Rr[t][r] = Rg[(size_t)s * 16 + col];
         if (Mg[(size_t)s * 16 + col] != 0.0) mb |= 1ull << (4 * t + r);
       }
@@ -85,14 +98,14 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
 #pragma unroll
     for (int r = 0; r < 4; r++) Rr[t][r] = ((mb >> (4 * t + r)) & 1ull) ? Rr[t][r] : 0.0;
   };
-  for (int e = tid; e < 16 * a.Mmax; e += 512) Lidx[e] = a.midx[(size_t)tile * 16 * a.Mmax + e];
+  for (int e = tid; e < 16 * a.Mmax; e += 512) Lidx[e] = (unsigned short)a.midx[(size_t)tile * 16 * a.Mmax + e];
   if (tid < 16) Lcnt[tid] = a.mcnt4[tile * 16 + tid];
   if (helper)
 #pragma unroll
     for (int v = 0; v < 5; v++) Lred[v * 256 + tid] = 0.0;
 
-  const double2 *XAw = a.XA + (size_t)(w * NT) * 128 + lane;   // + (b*NTT + t)*128 + h*64
-  const double2 *XUw = a.XU + (size_t)(w * NT) * 128 + lane;
+  const double2 *XAw = a.XA + (size_t)wt0 * 128 + lane;   // + (b*NTT + t)*128 + h*64
+  const double2 *XUw = a.XU + (size_t)wt0 * 128 + lane;
   const int kk_h = tile * 16 + hk;
   const bool kvalid = kk_h < a.q;
   const size_t tbase = (size_t)tile * a.p_pad * 16;
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
     for (int k = slot; k < 16; k += 6) {
       aq_d4 acc = (aq_d4){0, 0, 0, 0};
       const int n4 = Lcnt[k];
-      const int *ix = Lidx + k * a.Mmax + g;
+      const unsigned short *ix = Lidx + k * a.Mmax + g;
       for (int t = 0; t < n4; t += 4) {   // lists are padded to whole groups of 16 samples: 4 gathers in flight per step
         const int i0 = ix[4 * t], i1 = ix[4 * t + 4], i2 = ix[4 * t + 8], i3 = ix[4 * t + 12];
         const double x0 = xr[(size_t)i0 * 16], x1 = xr[(size_t)i1 * 16], x2 = xr[(size_t)i2 * 16], x3 = xr[(size_t)i3 * 16];
@@ -204,6 +217,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
     __syncthreads();
     if (helper) stage_commit(0);
 
+    bool dead = false;   // a bounded wait on a partner expired (reported through errflag)
     for (int b = 0; b < a.nb; b++) {
       const bool more = (b + 1 < a.nb);
       const int buf = b & 1;
@@ -213,6 +227,56 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
       aq_lds_barrier();
 
       if (w == 0) {
+        if (a.C > 1) {
+          // ---- sample split: publish this part's partial S, collect the others', add in fixed order ----
+          // All exchanged words are agent-scope atomics (sc1: written through to, and read from, the level the XCDs
+          // share), ordered by program order + s_waitcnt.  No release/acquire fence: at agent scope it writes back and
+          // invalidates this XCD's whole L2, where the X operand panels live.  The whole wave takes part (lane = 4
+          // entries of the 16x16 block) so that every load of a step is in flight at once.
+          double own[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int e = lane + 64 * r;
+            double v = Sp[e];
+#pragma unroll
+            for (int ww = 1; ww < NW; ww++) v += Sp[ww * 256 + e];
+            own[r] = v;
+          }
+          double *slot = a.Pbuf + ((size_t)(tile * 2 + buf) * a.C) * 256 + lane;
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            __hip_atomic_store(&slot[(size_t)part * 256 + 64 * r], own[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial is performed before the flag goes up
+          if (lane == 0) __hip_atomic_store(&a.pflag[tile * a.C + part], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while (!dead) {   // lane c polls part c's flag
+            int f = b + 1;
+            if (lane < a.C && lane != part) f = __hip_atomic_load(&a.pflag[tile * a.C + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(f >= b + 1)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) { *a.errflag = 1; dead = true; }   // give up for good: results are invalid
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // flags observed before the partials are requested
+          double tot[4] = {0.0, 0.0, 0.0, 0.0};
+          for (int c0 = 0; c0 < a.C; c0 += 4) {                // 16 loads in flight per step
+            double pv[4][4];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+              const int c2 = (c0 + cc < a.C) ? c0 + cc : part;  // out-of-range and own slots read this part's own (valid) slot
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                pv[cc][r] = __hip_atomic_load(&slot[(size_t)c2 * 256 + 64 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (c0 + cc < a.C) tot[r] += (c0 + cc == part) ? own[r] : pv[cc][r];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) Sp[lane + 64 * r] = tot[r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave reads it back below
+        }
         // ---- sequential pass over the 16 SNPs, lane = trait (src/coreLoop.cpp:115-133) ----
         if (lane < 16) {
           const double *Gk = LGk + buf * (256 * 17) + col;
@@ -220,8 +284,10 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
 #pragma unroll
           for (int j = 0; j < 16; j++) {
             double s = Sp[j * 16 + col];
+            if (a.C == 1) {
 #pragma unroll
-            for (int ww = 1; ww < NW; ww++) s += Sp[ww * 256 + j * 16 + col];
+              for (int ww = 1; ww < NW; ww++) s += Sp[ww * 256 + j * 16 + col];
+            }
             S[j] = s;
             if (j & 1) __builtin_amdgcn_sched_barrier(0);   // bound the LDS loads in flight (VGPR budget)
           }
@@ -267,8 +333,10 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
         double gm = Lgam[tid], mu = Lmu[tid];
         size_t off = tbase + (size_t)(16 * b) * 16 + tid;
         double gbv = 0.0;
-        a.gam[off] = gm;
-        a.mu[off] = mu;
+        if (lead) {
+          a.gam[off] = gm;
+          a.mu[off] = mu;
+        }
         if (kvalid && j < a.p) {
           double be = gm * mu;
           double m2 = (mu * mu + Ls2[tid]) * gm;              // update_m2_beta_, R/update_vb.R:19-31
@@ -283,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
         gbv += __shfl_xor(gbv, 4, 64);
         gbv += __shfl_xor(gbv, 2, 64);
         gbv += __shfl_xor(gbv, 1, 64);
-        if (hk == 0) a.rowGB[(size_t)tile * a.p_pad + j] = gbv;
+        if (hk == 0 && lead) a.rowGB[(size_t)tile * a.p_pad + j] = gbv;
       }
 
       // ---- R -= mis .* (X_b delta), and S of block b+1, tile by tile ----
@@ -326,7 +394,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
     for (int t = 0; t < NT; t++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        int s = 16 * (w * NT + t) + aq_drow(a.dmode, r, g);
+        int s = 16 * (wt0 + t) + aq_drow(a.dmode, r, g);
         double v = Rr[t][r];
         Rg[(size_t)s * 16 + col] = v;
         rn += v * v;
@@ -340,9 +408,10 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
     double r2 = 0.0;
 #pragma unroll 1
     for (int s = 0; s < NW * 4; s++) r2 += Lrn[s * 16 + tid];
-    a.sums[4 * Q + kk] = r2;
+    if (a.C > 1) a.rnpart[(size_t)part * Q + kk] = r2;   // added over the parts by aq_k_sum_parts
+    else a.sums[4 * Q + kk] = r2;
 #pragma unroll 1
-    for (int u = 0; u < 5; u++) {   // Lred rows: gam, m2, sx, gam*b, gam*log sig2_beta -> sums rows 0,1,2,3,5
+    for (int u = 0; u < 5 && lead; u++) {   // Lred rows: gam, m2, sx, gam*b, gam*log sig2_beta -> sums rows 0,1,2,3,5
       double acc2 = 0.0;
 #pragma unroll 1
       for (int jj = 0; jj < 16; jj++) acc2 += Lred[u * 256 + jj * 16 + tid];
@@ -362,4 +431,13 @@ __global__ void aq_k_build_xr(const double *__restrict__ X, double *__restrict__
   int b = (int)(rest / NR);
   int j = 16 * b + jj;
   XR[e] = (i < n && j < p) ? X[(size_t)i + (size_t)n * j] : 0.0;
+}
+
+// sums[4][k] = sum over the C sample parts of their ||R_k||^2 (fixed order)
+__global__ void aq_k_sum_parts(const double *__restrict__ rnpart, double *__restrict__ dst, int C, int q_pad) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= q_pad) return;
+  double s = 0.0;
+  for (int c = 0; c < C; c++) s += rnpart[(size_t)c * q_pad + k];
+  dst[k] = s;
 }

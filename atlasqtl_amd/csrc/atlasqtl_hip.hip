@@ -144,6 +144,9 @@ struct aq_vb {
   double *XR = nullptr;  // [nb][NR][16] row-major SNP panels (gather source of the per-trait Gram corrections)
   int *midx = nullptr, *mcnt4 = nullptr;   // per-trait lists of missing samples
   int Mmax = 0, NR = 0;
+  int misC = 1;          // masked kernel: workgroups (sample parts) per trait tile
+  double *Pbuf = nullptr, *rnpart = nullptr;
+  int *pflag = nullptr;
   double *Xcm = nullptr, *mis = nullptr, *XN = nullptr;
   int ncu = 256;
   int nseg = 1, ngroup = 1; // SNP segments x trait-tile groups (streams) of the full-sweep launches
@@ -180,7 +183,7 @@ struct aq_vb {
 static void aq_free_all(aq_vb *s) {
   if (!s) return;
   hipSetDevice(s->device);
-  void *ptrs[] = {s->XR, s->midx, s->mcnt4, s->Xcm, s->mis, s->XN, s->XA, s->XU, s->G, s->Gx, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
+  void *ptrs[] = {s->Pbuf, s->rnpart, s->pflag, s->XR, s->midx, s->mcnt4, s->Xcm, s->mis, s->XN, s->XA, s->XU, s->G, s->Gx, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
                   s->eta_h, s->kappa_h, s->n0, s->nobs, s->zeta, s->tau, s->sig2b, s->log_tau, s->eta_vb, s->kappa_vb,
                   s->coef, s->inv2s, s->cst, s->sums, s->rowA, s->rowGB, s->Aarr, s->Barr, s->colApart, s->Hpart, s->sc};
   for (void *ptr : ptrs)
@@ -251,14 +254,19 @@ static int aq_launch_mis(aq_vb *s, int mode, double c) {
   t.midx = s->midx; t.mcnt4 = s->mcnt4; t.sums = s->sums; t.rowGB = s->rowGB; t.c = c;
   t.p = s->p; t.q = s->q; t.p_pad = s->p_pad; t.q_pad = s->q_pad; t.n_pad = s->n_pad; t.nb = s->nb; t.ntile = s->ntile;
   t.dmode = s->dmode; t.mode = mode; t.NR = s->NR; t.Mmax = s->Mmax;
-  size_t lds = (size_t)(8 * 256 + 11 * 256 + 5 * 256 + 8 * 4 * 16 + 2 * 256 * 17) * sizeof(double) + (size_t)(16 * s->Mmax + 16) * sizeof(int);
+  t.C = s->misC; t.Pbuf = s->Pbuf; t.pflag = s->pflag; t.errflag = s->errflag; t.rnpart = s->rnpart;
+  if (s->misC > 1) AQ_HIP(hipMemsetAsync(s->pflag, 0, (size_t)s->ntile * s->misC * sizeof(int), 0));
+  size_t lds = (size_t)(8 * 256 + 11 * 256 + 5 * 256 + 8 * 4 * 16 + 2 * 256 * 17) * sizeof(double) + 16 * sizeof(int) +
+               (size_t)16 * s->Mmax * sizeof(unsigned short);
 #define AQ_MIS(NT_)                                                                                             \
   if (s->NT == NT_) {                                                                                          \
     AQ_HIP(hipFuncSetAttribute((const void *)aq_core_sweep_mis_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((aq_core_sweep_mis_kernel<NT_>), dim3(s->ntile), dim3(512), lds, 0, t);                \
+    hipLaunchKernelGGL((aq_core_sweep_mis_kernel<NT_>), dim3(s->ntile * s->misC), dim3(512), lds, 0, t);     \
   } else
   AQ_MIS(1) AQ_MIS(2) AQ_MIS(4) AQ_MIS(8) AQ_MIS(16) { return aq_fail(AQ_ERR_UNSUPPORTED, "no masked MFMA kernel instantiation for this n"); }
 #undef AQ_MIS
+  if (s->misC > 1)
+    hipLaunchKernelGGL(aq_k_sum_parts, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->rnpart, s->sums + (size_t)4 * s->q_pad, s->misC, s->q_pad);
   AQ_HIP(hipGetLastError());
   return AQ_OK;
 }
@@ -425,6 +433,11 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   s->q_pad = (pr->q + 15) / 16 * 16;
   s->nb = s->p_pad / 16;
   s->ntile = s->q_pad / 16;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, pr->device) == hipSuccess && prop.multiProcessorCount > 0) s->ncu = prop.multiProcessorCount;
+    if (const char *e = getenv("AQ_NCU")) s->ncu = atoi(e) > 0 ? atoi(e) : s->ncu;
+  }
   // residual tile geometry: n_pad = 16 * NT * NW samples
   if (pr->n <= 128) { s->NT = 2; s->NW = 4; }
   else if (pr->n <= 256) { s->NT = 4; s->NW = 4; }
@@ -444,10 +457,31 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         if (m > max_missing) max_missing = m;
       }
     }
-    if (has_missing && pr->n <= 2048 && max_missing <= AQ_MIS_MMAX && !(ek && atoi(ek) == 2)) {
+    // the masked MFMA kernel also serves complete Y beyond the look-ahead kernel's n (all-ones mask, empty lists)
+    if ((has_missing || pr->n > 1056) && pr->n <= 16384 && max_missing <= AQ_MIS_MMAX && !(ek && atoi(ek) == 2)) {
       s->use_mis = true;
       s->NW = 8;
-      s->NT = pr->n <= 128 ? 1 : pr->n <= 256 ? 2 : pr->n <= 512 ? 4 : pr->n <= 1024 ? 8 : 16;
+      // n_pad = 128 NT C: C workgroups per trait tile, NT in {1,2,4,8,16} residual tiles per wave.  Model of a sweep:
+      // whole rounds of workgroups (one per CU) x time per SNP block (4.5 + 0.94 NT us, + 6 us for the exchange)
+      {
+        const int ntile_ = (pr->q + 15) / 16;
+        double best = 1e300;
+        for (int C = 1; C <= 8; C++)
+          for (int NT = 1; NT <= 16; NT *= 2) {
+            if (128 * NT * C < pr->n) continue;
+            double rounds = (double)(((long long)ntile_ * C + s->ncu - 1) / s->ncu);
+            double cost = rounds * (4.5 + 0.94 * NT + (C > 1 ? 6.0 : 0.0));
+            if (cost < best - 1e-9) { best = cost; s->misC = C; s->NT = NT; }
+          }
+      }
+      if (const char *e = getenv("AQ_MIS_C")) {   // test hook: force the sample split at small n
+        int C = atoi(e);
+        if (C >= 1 && C <= 8) {
+          s->misC = C;
+          s->NT = 16;
+          for (int NT = 16; NT >= 1; NT /= 2) if (128 * NT * C >= pr->n) s->NT = NT;
+        }
+      }
       s->Mmax = (max_missing + 15) / 16 * 16;
       if (s->Mmax < 16) s->Mmax = 16;
     } else if (has_missing || (ek && atoi(ek) == 2) || pr->n > 1056) {
@@ -497,7 +531,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     }
   }
   if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
-  if (s->use_mis) s->NR = s->n_pad + 8;
+  if (s->use_mis) { s->n_pad = 128 * s->NT * s->misC; s->NR = s->n_pad + 8; }
   if (s->use_tw) {
     s->n_pad = 64 * s->NE * s->WPT;
     // SNP columns staged in LDS at a time: ns * n_pad doubles next to 18 KB of block scalars, within 160 KB
@@ -509,11 +543,6 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 3 ? 3 : 1;
   else if (s->NW == 4 && s->ntile > 512) s->TT = 3;
   if (s->NW != 4 || s->use_la || s->use_mis) s->TT = 1;
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, pr->device) == hipSuccess && prop.multiProcessorCount > 0) s->ncu = prop.multiProcessorCount;
-    if (const char *e = getenv("AQ_NCU")) s->ncu = atoi(e) > 0 ? atoi(e) : s->ncu;
-  }
   int rc = aq_probe_dmode(&s->dmode);
   if (rc != AQ_OK) { delete s; return rc; }
 
@@ -523,7 +552,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   s->has_anneal = pr->has_anneal != 0;
   std::memcpy(s->anneal, pr->anneal, sizeof(s->anneal));
   s->tol = pr->tol; s->maxit = pr->maxit; s->thinned = pr->thinned_elbo_eval != 0; s->debug = pr->debug != 0;
-  s->has_missing = has_missing;
+  s->has_missing = has_missing || s->use_mis;   // the masked kernel produces the NA forms of the column sums (identical for complete Y)
 
   auto fail = [&](int code) { aq_free_all(s); return code; };
 #define AQ_TRYF(x) do { int rc2_ = (x); if (rc2_ != AQ_OK) return fail(rc2_); } while (0)
@@ -544,6 +573,9 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     AQ_TRYF(aq_dalloc(&s->XR, (size_t)s->nb * s->NR * 16));
     AQ_TRYF(aq_dalloc(&s->midx, (size_t)s->ntile * 16 * s->Mmax));
     AQ_TRYF(aq_dalloc(&s->mcnt4, (size_t)s->ntile * 16));
+    AQ_TRYF(aq_dalloc(&s->Pbuf, (size_t)s->ntile * 2 * s->misC * 256));
+    AQ_TRYF(aq_dalloc(&s->pflag, (size_t)s->ntile * s->misC));
+    AQ_TRYF(aq_dalloc(&s->rnpart, (size_t)s->misC * s->q_pad));
     // lists of missing samples per trait, padded to groups of 16 with the all-zero row n_pad of XR
     std::vector<int> idx((size_t)s->ntile * 16 * s->Mmax, s->n_pad), cnt((size_t)s->ntile * 16, 0);
     for (int k = 0; k < s->q; k++) {

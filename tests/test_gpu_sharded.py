@@ -140,10 +140,33 @@ def test_generic_kernel_split_traits_matches_oracle(shape, na, wpt, monkeypatch)
 
 @pytest.mark.parametrize("shape,na", [((2500, 40, 20), 0.05), ((5000, 24, 17), 0.05), ((5200, 20, 9), 0.0)])
 def test_large_n_matches_oracle(shape, na):
-    """n beyond the register-resident MFMA kernels (C5 has n = 5000 and a missingness mask): 2 and 4 waves per trait."""
+    """n beyond one workgroup's registers (C5 has n = 5000 and a missingness mask): the masked MFMA kernel with the
+    sample axis split over 5 / 5 / 3 cooperating workgroups per trait tile; complete Y takes the same kernel."""
     from tests.util import make_problem
     n, p, q = shape
-    _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q)
+    _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q, kernel=3)
+
+
+@pytest.mark.parametrize("shape,na", [((2500, 40, 20), 0.05), ((5000, 24, 17), 0.05)])
+def test_large_n_generic_kernel_matches_oracle(shape, na, monkeypatch):
+    """The generic kernel's 2 / 4 waves-per-trait geometry at its natural sizes (forced with AQ_KERNEL=2)."""
+    from tests.util import make_problem
+    monkeypatch.setenv("AQ_KERNEL", "2")
+    n, p, q = shape
+    _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q, kernel=2)
+
+
+@pytest.mark.parametrize("C", [2, 3, 5])
+@pytest.mark.parametrize("shape,na", [((300, 130, 49), 0.04), ((200, 90, 33), 0.0)])
+def test_masked_kernel_sample_split_matches_oracle(shape, na, C, monkeypatch):
+    """The cross-workgroup exchange of partial S (release/acquire flags, redundant recursion) forced at small n."""
+    from tests.util import make_problem
+    monkeypatch.setenv("AQ_MIS_C", str(C))
+    n, p, q = shape
+    prob = make_problem(n, p, q, p_act=8, prob_assoc=0.3, na_frac=na)
+    if na == 0.0:   # complete Y reaches the masked kernel only beyond the look-ahead kernel's n; poke one NaN in
+        prob["Y"][3, 1] = np.nan
+    _check_against_oracle(prob, q, kernel=3)
 
 
 @pytest.mark.parametrize("shape,na", [((70, 17, 1), 0.1), ((128, 40, 16), 0.3), ((200, 90, 33), 0.08), ((300, 130, 49), 0.02),
@@ -157,8 +180,8 @@ def test_masked_mfma_kernel_matches_oracle(shape, na):
 
 
 def test_missing_beyond_index_list_capacity_falls_back_to_generic():
-    """More than AQ_MIS_MMAX = 512 missing samples in a trait: the generic kernel takes over (core_kernel == 2)."""
+    """More than AQ_MIS_MMAX = 1024 missing samples in a trait: the generic kernel takes over (core_kernel == 2)."""
     from tests.util import make_problem
-    prob = make_problem(1500, 24, 5, p_act=4, prob_assoc=1.0, na_frac=0.4)
-    assert np.isnan(prob["Y"]).sum(axis=0).max() > 512
+    prob = make_problem(3000, 24, 5, p_act=4, prob_assoc=1.0, na_frac=0.4)
+    assert np.isnan(prob["Y"]).sum(axis=0).max() > 1024
     _check_against_oracle(prob, 5, kernel=2)

@@ -61,6 +61,10 @@ if __name__ == "__main__":
         timing(1000, 4000, 4096, sweeps=2, na_frac=0.05)
         timing(500, 4000, 4096, sweeps=2, na_frac=0.05)
         timing(2000, 2000, 4096, sweeps=2, na_frac=0.05)
+    if what == "misbig":   # sample-split masked kernel at C5-like n
+        timing(5000, 2000, 2512, sweeps=2, na_frac=0.05)
+        timing(5000, 2000, 2512, sweeps=2)
+        timing(2000, 2000, 4096, sweeps=2)
     if what == "bign":   # generic kernel beyond n = 2048 (C5-like n, reduced p and q)
         timing(1000, 4000, 4096, sweeps=2, na_frac=0.05)
         timing(5000, 2000, 2512, sweeps=2, na_frac=0.05)
