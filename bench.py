@@ -67,9 +67,13 @@ def build_problem(n, p, q_total, k0, k1, device, seed=123):
     Y -= Y.mean(axis=0)
     p0 = (5.0, 25.0)
     lh = H.auto_set_hyper_(Y, p, p0)
+    na = float(os.environ.get("AQ_BENCH_NA", "0"))   # fraction of Y missing completely at random (C5's missingness mask)
+    if na > 0:
+        Y[rng.random(Y.shape) < na] = np.nan
+        Y -= np.nanmean(Y, axis=0)                    # centring on the observed entries, R/prepare_atlasqtl.R:70-73
     irng = np.random.default_rng(seed + 333)
     t02, n0 = lh["t02"], float(lh["n0"][0])
-    tau = 1.0 / float(np.median(Y.var(axis=0, ddof=1)))
+    tau = 1.0 / float(np.median(np.nanvar(Y, axis=0, ddof=1)))
     sig02_inv = float(irng.gamma(shape=max(p, q_total)))
     li = dict(sig02_inv_vb=sig02_inv,
               sig2_beta_vb=1.0 / irng.gamma(shape=2.0, scale=1e-2 * tau, size=q_total),
@@ -252,7 +256,8 @@ def main():
                        "n": n, "p": p, "q": q, "q_per_gpu": q_loc, "parallelism": f"trait-sharded x{world}",
                        "elbo_evals_in_timed_region": st1["n_elbo"] - st0["n_elbo"], "elbo_last": st1["lb_opt"],
                        "setup_s": round(t_setup, 1)},
-            "roofline": {"bound": "mfma", "kernel": "aq_core_sweep_la_kernel", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": {0: "aq_core_sweep_la_kernel", 1: "aq_core_sweep_kernel", 2: "aq_trait_wave_kernel",
+                                                     3: "aq_core_sweep_mis_kernel"}[st1["core_kernel"]], "achieved": achieved,
                          "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,
                          "traffic": PMC_TRAFFIC_C3_BYTES if (n, p, q, world) == (1000, 50000, 10000, 1) else None,
                          "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic_v3.txt)",
