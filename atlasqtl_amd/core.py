@@ -232,6 +232,23 @@ class VbRun:
         self.advance_until_done()
         check(lib().aq_vb_set_sweep_budget(self.h, -1), "aq_vb_set_sweep_budget")
 
+    def get_state(self):
+        """The complete loop state between two sweeps as one uint8 array (aq_vb_get_state): unlike the reference's
+        write-only checkpoint_ (R/utils.R:571-611), `set_state` on a handle created for the same problem continues
+        bit-identically."""
+        L = lib()
+        if self.status()["it"] == 0:
+            self.run_sweeps(0)          # initial residual and column sums, no sweep
+        nbytes = L.aq_vb_state_bytes(self.h)
+        buf = np.empty(int(nbytes), dtype=np.uint8)
+        check(L.aq_vb_get_state(self.h, buf.ctypes.data_as(C.c_void_p), buf.size), "aq_vb_get_state")
+        return buf
+
+    def set_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        check(lib().aq_vb_set_state(self.h, buf.ctypes.data_as(C.c_void_p), buf.size), "aq_vb_set_state")
+        return self
+
     def status(self):
         st = AqVbStatus()
         check(lib().aq_vb_get_status(self.h, C.byref(st)), "aq_vb_get_status")
@@ -264,9 +281,43 @@ class VbRun:
         return out
 
 
+def _run_with_checkpoints(run, checkpoint_path, rate, maxit):
+    """checkpoint_ / checkpoint_clean_up_ (R/utils.R:571-627, R/atlasqtl_global_local_core.R:379,388): every `rate`
+    iterations write the reference's temporary output list (tmp_output_it_<it>.npz: beta_vb, gam_vb, theta_vb, zeta_vb,
+    converged, it, lb_new, diff_lb, lam2_inv_vb, sig02_inv_vb) and keep only the last two; remove them all at the end.
+    Beside each, hip_state_it_<it>.npy holds the complete device state for `resume_from` (the reference cannot resume)."""
+    import glob
+    import os
+    if not os.path.isdir(checkpoint_path):
+        raise ValueError("The directory specified in checkpoint_path does not exist. ")       # R/prepare_atlasqtl.R:21-22
+    rank = 0 if run.pg is None else __import__("torch").distributed.get_rank(run.pg)
+    tag = "" if run.pg is None else f"_rank{rank}"
+    while True:
+        st = run.status()
+        if st["converged"] or st["it"] >= maxit:
+            break
+        run.run_sweeps(rate - st["it"] % rate)
+        st = run.status()
+        it = st["it"]
+        if it % rate == 0 and not st["converged"]:
+            res = run.result(full_output=True)
+            np.savez(os.path.join(checkpoint_path, f"tmp_output_it_{it}{tag}.npz"), beta_vb=res["beta_vb"],
+                     gam_vb=res["gam_vb"], theta_vb=res["theta_vb"], zeta_vb=res["zeta_vb"], converged=bool(st["converged"]),
+                     it=it, lb_new=st["lb_opt"], diff_lb=st["diff_lb"], lam2_inv_vb=res["lam2_inv_vb"],
+                     sig02_inv_vb=st["sig02_inv_vb"])
+            np.save(os.path.join(checkpoint_path, f"hip_state_it_{it}{tag}.npy"), run.get_state())
+            for stem in (f"tmp_output_it_{it - 2 * rate}{tag}.npz", f"hip_state_it_{it - 2 * rate}{tag}.npy"):
+                old = os.path.join(checkpoint_path, stem)          # keep only the last two for comparison
+                if os.path.exists(old):
+                    os.remove(old)
+    for f in glob.glob(os.path.join(checkpoint_path, f"tmp_output_it_*{tag}.npz")):
+        os.remove(f)
+
+
 def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbose, list_hyper, list_init,
                                 checkpoint_path=None, trace_path=None, full_output=False, thinned_elbo_eval=True,
-                                debug=False, batch="y", device=0, process_group=None):
+                                debug=False, batch="y", device=0, process_group=None, resume_from=None,
+                                checkpoint_rate=100):
     """R/atlasqtl_global_local_core.R:8-433 on the GPU.  Returns the reference's list
     (:426-428): beta_vb, gam_vb, theta_vb, zeta_vb, n, p, q, anneal, converged, it, maxit,
     tol, lb_opt, diff_lb (+ the variational parameters with full_output).
@@ -277,12 +328,17 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbo
         raise NotImplementedError("df != 1 is unreachable from atlasqtl() (df <- 1, R/atlasqtl.R:272)")
     if batch != "y":
         raise ValueError("Batch scheme not defined. Exit.")            # :231
-    if checkpoint_path is not None or trace_path is not None:
-        raise NotImplementedError("checkpoint_path / trace_path are outside the accelerated path")
+    if trace_path is not None:
+        raise NotImplementedError("trace_path (trace plots) is outside the accelerated path")
     run = VbRun(Y, X, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval, debug, device=device,
                 q_total=int(shr_fac_inv), process_group=process_group)
     try:
-        run.run()
+        if resume_from is not None:
+            run.set_state(np.load(resume_from))
+        if checkpoint_path is None:
+            run.run()
+        else:
+            _run_with_checkpoints(run, checkpoint_path, checkpoint_rate, maxit)
         st = run.status()
         if verbose != 0:
             if st["converged"]:

@@ -942,6 +942,96 @@ static void aq_resolve_events(aq_vb *s) {
   s->ev.clear();
 }
 
+// ------------------------------------------------------ checkpoint / resume ----
+// The reference's checkpoint_ (R/utils.R:571-611) only writes outputs; it cannot resume.  Here the complete loop state
+// between two sweeps is one flat blob: header, host-side loop scalars, ELBO trace, then the device arrays the next
+// sweep reads (gam, mu, the incrementally updated residual, p- and q-vectors, column sums, AqScalars).  A, b and the row
+// sums of the pre-pass are not stored: the next sweep recomputes them from theta and zeta (same kernel, same bits).
+struct AqStateHeader {
+  uint64_t magic;        // "AQVBST01"
+  int32_t n, p, q, q_total, p_pad, q_pad, n_pad, core_kernel;
+  int32_t it, converged, annealing, ind_batch_conv, batch_conv, failed, n_trace, has_missing;
+  double c, c_s, sig2_zeta, lb_new, lb_old;
+};
+static const uint64_t AQ_STATE_MAGIC = 0x31305453425651ull | ((uint64_t)'A' << 56);
+
+struct AqStateSeg { void *ptr; size_t bytes; };
+static std::vector<AqStateSeg> aq_state_segments(aq_vb *s) {
+  const size_t pq = (size_t)s->ntile * s->p_pad * 16 * sizeof(double);
+  const size_t P = (size_t)s->p_pad * sizeof(double), Q = (size_t)s->q_pad * sizeof(double);
+  std::vector<AqStateSeg> v = {
+      {s->gam, pq}, {s->mu, pq}, {s->R, (size_t)s->ntile * s->n_pad * 16 * sizeof(double)},
+      {s->theta, P}, {s->sig2_theta, P}, {s->L, P}, {s->lam2_inv, P}, {s->Q, P},
+      {s->zeta, Q}, {s->tau, Q}, {s->sig2b, Q}, {s->log_tau, Q}, {s->eta_vb, Q}, {s->kappa_vb, Q},
+      {s->coef, Q}, {s->inv2s, Q}, {s->cst, Q}, {s->sums, 6 * Q}, {s->sc, sizeof(AqScalars)}};
+  return v;
+}
+static int aq_core_kernel_id(const aq_vb *s) { return s->use_mis ? 3 : s->use_tw ? 2 : s->use_la ? 0 : 1; }
+
+extern "C" int64_t aq_vb_state_bytes(aq_vb_handle s) {
+  if (!s) return -1;
+  size_t tot = sizeof(AqStateHeader) + s->trace_it.size() * (sizeof(int32_t) + sizeof(double));
+  for (auto &g : aq_state_segments(s)) tot += g.bytes;
+  return (int64_t)tot;
+}
+
+extern "C" int aq_vb_get_state(aq_vb_handle s, void *buf, int64_t cap) {
+  if (!s || !buf) return aq_fail(AQ_ERR_ARG, "NULL argument");
+  if (s->phase != 2) return aq_fail(AQ_ERR_ARG, "aq_vb_get_state: only between sweeps (after aq_vb_run / aq_vb_run_sweeps returned)");
+  if (cap < aq_vb_state_bytes(s)) return aq_fail(AQ_ERR_ARG, "aq_vb_get_state: buffer too small");
+  AQ_HIP(hipSetDevice(s->device));
+  AQ_HIP(hipDeviceSynchronize());
+  AQ_TRY(aq_check_chain_error(s));
+  AqStateHeader h;
+  std::memset(&h, 0, sizeof(h));
+  h.magic = AQ_STATE_MAGIC;
+  h.n = s->n; h.p = s->p; h.q = s->q; h.q_total = s->q_total; h.p_pad = s->p_pad; h.q_pad = s->q_pad; h.n_pad = s->n_pad;
+  h.core_kernel = aq_core_kernel_id(s);
+  h.it = s->it; h.converged = s->converged; h.annealing = s->annealing; h.ind_batch_conv = s->ind_batch_conv;
+  h.batch_conv = s->batch_conv; h.failed = s->failed; h.n_trace = (int32_t)s->trace_it.size(); h.has_missing = s->has_missing;
+  h.c = s->c; h.c_s = s->c_s; h.sig2_zeta = s->sig2_zeta; h.lb_new = s->lb_new; h.lb_old = s->lb_old;
+  char *o = (char *)buf;
+  std::memcpy(o, &h, sizeof(h)); o += sizeof(h);
+  for (int i = 0; i < h.n_trace; i++) { int32_t v = s->trace_it[i]; std::memcpy(o, &v, sizeof(v)); o += sizeof(v); }
+  for (int i = 0; i < h.n_trace; i++) { double v = s->trace_lb[i]; std::memcpy(o, &v, sizeof(v)); o += sizeof(v); }
+  for (auto &g : aq_state_segments(s)) {
+    AQ_HIP(hipMemcpy(o, g.ptr, g.bytes, hipMemcpyDeviceToHost));
+    o += g.bytes;
+  }
+  return AQ_OK;
+}
+
+extern "C" int aq_vb_set_state(aq_vb_handle s, const void *buf, int64_t len) {
+  if (!s || !buf) return aq_fail(AQ_ERR_ARG, "NULL argument");
+  if (len < (int64_t)sizeof(AqStateHeader)) return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: truncated state");
+  AqStateHeader h;
+  const char *o = (const char *)buf;
+  std::memcpy(&h, o, sizeof(h)); o += sizeof(h);
+  if (h.magic != AQ_STATE_MAGIC) return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: not an atlasqtl-hip state blob");
+  if (h.n != s->n || h.p != s->p || h.q != s->q || h.q_total != s->q_total || h.p_pad != s->p_pad || h.q_pad != s->q_pad ||
+      h.n_pad != s->n_pad || h.core_kernel != aq_core_kernel_id(s) || h.has_missing != (int)s->has_missing)
+    return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state was saved for a different problem shape or kernel geometry");
+  size_t need = sizeof(h) + (size_t)h.n_trace * (sizeof(int32_t) + sizeof(double));
+  for (auto &g : aq_state_segments(s)) need += g.bytes;
+  if (h.n_trace < 0 || (int64_t)need != len) return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: state size mismatch");
+  AQ_HIP(hipSetDevice(s->device));
+  AQ_HIP(hipDeviceSynchronize());
+  s->trace_it.resize(h.n_trace);
+  s->trace_lb.resize(h.n_trace);
+  for (int i = 0; i < h.n_trace; i++) { int32_t v; std::memcpy(&v, o, sizeof(v)); o += sizeof(v); s->trace_it[i] = v; }
+  for (int i = 0; i < h.n_trace; i++) { double v; std::memcpy(&v, o, sizeof(v)); o += sizeof(v); s->trace_lb[i] = v; }
+  for (auto &g : aq_state_segments(s)) {
+    AQ_HIP(hipMemcpy(g.ptr, o, g.bytes, hipMemcpyHostToDevice));
+    o += g.bytes;
+  }
+  s->it = h.it; s->converged = h.converged != 0; s->annealing = h.annealing != 0; s->ind_batch_conv = h.ind_batch_conv;
+  s->batch_conv = h.batch_conv; s->failed = h.failed != 0;
+  s->c = h.c; s->c_s = h.c_s; s->sig2_zeta = h.sig2_zeta; s->lb_new = h.lb_new; s->lb_old = h.lb_old;
+  s->pre_done = false;   // the next sweep recomputes the pre-pass from the restored theta / zeta
+  s->phase = 2;
+  return AQ_OK;
+}
+
 extern "C" int aq_vb_get_status(aq_vb_handle s, aq_vb_status *st) {
   if (!s || !st) return aq_fail(AQ_ERR_ARG, "NULL argument");
   AQ_HIP(hipSetDevice(s->device));
@@ -961,7 +1051,7 @@ extern "C" int aq_vb_get_status(aq_vb_handle s, aq_vb_status *st) {
   st->sig02_inv_vb = h.sig02_inv;
   st->sig2_inv_vb = h.sig2_inv;
   st->lentz_iters = h.lentz_iters;
-  st->core_kernel = s->use_mis ? 3 : s->use_tw ? 2 : s->use_la ? 0 : 1;
+  st->core_kernel = aq_core_kernel_id(s);
   return AQ_OK;
 }
 

@@ -167,6 +167,18 @@ int aq_vb_get_result(aq_vb_handle h, double *beta_vb, double *gam_vb, double *mu
                      double *sig2_beta_vb);
 
 /* ------------------------------------------------------------------------------------------
+ * Checkpoint / resume.  The reference's checkpoint_ (R/utils.R:571-611, called at
+ * R/atlasqtl_global_local_core.R:379) only writes outputs every 100 iterations and cannot resume; these
+ * entries capture and restore the COMPLETE loop state between two sweeps (valid after aq_vb_run /
+ * aq_vb_run_sweeps returned, or between aq_vb_advance calls that returned AQ_VB_DONE), so that a
+ * restored handle continues bit-identically.  The handle receiving the state must have been created
+ * for the same X, Y, hyper-parameters and device geometry (any list_init): shapes are checked.
+ * ---------------------------------------------------------------------------------------- */
+int64_t aq_vb_state_bytes(aq_vb_handle h);
+int aq_vb_get_state(aq_vb_handle h, void *buf, int64_t cap);
+int aq_vb_set_state(aq_vb_handle h, const void *buf, int64_t len);
+
+/* ------------------------------------------------------------------------------------------
  * Test hooks for the fp64 special functions the path uses (host evaluation of the same
  * header the kernels compile): which = 0 log_ndtr, 1 digamma, 2 expint_E1 (x<=1),
  * 3 gamma_inc_upper(a=x2, x), 4 sigmoid_neg, 5 / 6 log Phi / log(1-Phi) and 7 / 8 the inverse Mills

@@ -88,3 +88,75 @@ def test_argument_errors_keep_reference_wording():
         A.atlasqtl(Y, X, (3, 9), anneal=(7, 2, 10), verbose=0)
     with pytest.raises(A.AtlasqtlError, match="same number of samples"):
         A.atlasqtl(Y[:50], X, (3, 9), verbose=0)
+
+
+def _vbrun(prob, li=None, **kw):
+    from atlasqtl_amd.core import VbRun
+    return VbRun(prob["Y"], prob["X"], prob["list_hyper"], li if li is not None else prob["list_init"], (1, 2, 10), 0.1, 400,
+                 True, True, **kw)
+
+
+@pytest.mark.parametrize("na", [0.0, 0.06])
+def test_state_roundtrip_continues_bit_identically(na):
+    """aq_vb_get_state / aq_vb_set_state (the reference's checkpoint_ is write-only, R/utils.R:571-611):
+    a second handle, created with DIFFERENT initial values, continues from the captured state to the very same bits."""
+    from tests.util import make_problem
+    prob = make_problem(200, 130, 49, p_act=10, prob_assoc=0.3, na_frac=na)
+    a = _vbrun(prob).run()
+    ref_tr, ref = a.elbo_trace(), a.result(full_output=True)
+    ref_st = a.status()
+    a.close()
+    for stop in (0, 7, 23):           # before the first sweep, inside the annealing ladder, on the thinned ELBO schedule
+        b = _vbrun(prob)
+        b.run_sweeps(stop)
+        blob = b.get_state()
+        b.close()
+        li2 = dict(prob["list_init"])
+        li2["gam_vb"] = np.asfortranarray(np.full_like(prob["list_init"]["gam_vb"], 0.3))
+        li2["theta_vb"] = prob["list_init"]["theta_vb"] * 0.0
+        c = _vbrun(prob, li2).set_state(blob)
+        assert c.status()["it"] == stop
+        c.run()
+        st, tr, res = c.status(), c.elbo_trace(), c.result(full_output=True)
+        c.close()
+        assert st["it"] == ref_st["it"] and st["converged"] == ref_st["converged"] and st["lb_opt"] == ref_st["lb_opt"]
+        np.testing.assert_array_equal(tr[0], ref_tr[0])
+        np.testing.assert_array_equal(tr[1], ref_tr[1])
+        for k in ("gam_vb", "mu_beta_vb", "theta_vb", "zeta_vb", "tau_vb", "lam2_inv_vb"):
+            np.testing.assert_array_equal(res[k], ref[k])
+
+
+def test_state_of_another_problem_is_refused():
+    from atlasqtl_amd._lib import AtlasqtlHipError as AqError
+    from tests.util import make_problem
+    a = _vbrun(make_problem(200, 130, 49, p_act=10))
+    blob = a.get_state()
+    a.close()
+    b = _vbrun(make_problem(200, 131, 49, p_act=10))
+    with pytest.raises(AqError, match="different problem shape"):
+        b.set_state(blob)
+    with pytest.raises(AqError, match="not an atlasqtl-hip state blob"):
+        b.set_state(np.zeros(4096, dtype=np.uint8))
+    b.close()
+
+
+def test_checkpoint_path_and_resume(tmp_path):
+    """checkpoint_path as in R/atlasqtl.R:183: temporary outputs every `rate` iterations, the last two kept, all removed
+    at the end (R/utils.R:571-627) -- plus the state files that make `resume_from` possible."""
+    import os
+    import atlasqtl_amd as A
+    from tests.util import make_problem
+    prob = make_problem(200, 130, 49, p_act=10, prob_assoc=0.3)
+    args = (prob["Y"], prob["X"], 49, (1, 2, 10), 1, 0.1, 400, 0, prob["list_hyper"], prob["list_init"])
+    ref = A.atlasqtl_global_local_core_(*args, full_output=True)
+    got = A.atlasqtl_global_local_core_(*args, full_output=True, checkpoint_path=str(tmp_path), checkpoint_rate=10)
+    assert got["it"] == ref["it"] > 30
+    np.testing.assert_array_equal(got["gam_vb"], ref["gam_vb"])
+    files = sorted(os.listdir(tmp_path))
+    assert not [f for f in files if f.startswith("tmp_output_it_")]          # checkpoint_clean_up_
+    states = [f for f in files if f.startswith("hip_state_it_")]
+    assert len(states) == 2                                                   # the last two
+    again = A.atlasqtl_global_local_core_(*args, full_output=True, resume_from=os.path.join(tmp_path, states[0]))
+    assert again["it"] == ref["it"]
+    np.testing.assert_array_equal(again["gam_vb"], ref["gam_vb"])
+    np.testing.assert_array_equal(again["elbo_trace"][1], ref["elbo_trace"][1])
