@@ -65,6 +65,10 @@ struct AqCoreArgs {
   int nseg;              // > 1: chained-segment launch, block s*ntile + k = SNP segment s of trait tile k
   int *done;             // chained segments: done[tile] = number of that tile's segments already finished
   int *errflag;          // set when a bounded wait on done[] expires (results invalid, reported to the host)
+  const double *theta;   // look-ahead kernel (fused pre-pass): theta_vb [p_pad], zeta_vb [q_pad] of this sweep
+  const double *zeta;
+  double sqrt_c;         // annealing: the Mills ratios are taken at sqrt(c) (theta_j + zeta_k), R/update_vb.R:219-224
+  int c_is_one;
   int wt_base[16];       // look-ahead kernel: first residual tile of each matrix wave ...
   int wt_cnt[16];        // ... and how many it owns (uneven: the wave sharing a SIMD with the recurrence wave gets fewer)
 };

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   __shared__ double LA[2][256];        // A = log(1-Phi) - log Phi
   __shared__ double Lm1[2][256];       // old m1 = gam*mu
   __shared__ double LB[2][256];        // slope b of Z
+  __shared__ double Laa[2][256];       // intercept a of Z (Z = a + gam b, R/update_vb.R:217-234)
   __shared__ double LG[2][512];        // X_b'X_b as [16][32], upper 16 columns zero
   __shared__ double LGx[2][256];       // X_b'X_{b-1}  [j][i]
   __shared__ double Lgam[2][256], Lmu[2][256], Ldel[2][256];
@@ -166,18 +167,46 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   } else if (helper) {
     // =========================== helper wave ===============================================
     // global -> registers a phase ahead -> LDS; stores and column / row sums of finished blocks
-    double st_A[4], st_g[4], st_m[4], st_B[4], st_G[4], st_Gx[4];
-    auto stage_load = [&](int b) {
+    // The transcendental per-entry inputs of the block are computed HERE, a phase ahead, from theta_j + zeta_k (the work
+    // of the former p x q pre-pass kernel, which wrote and re-read 16 B per entry):
+    //   A = log(1-Phi(u)) - log Phi(u)      src/coreLoop.cpp:75-76 (its log_Phi / log_1_min_Phi inputs, R/...core.R:293-295)
+    //   Z = a + gam b,  a = u + imr0/sqrt(c), b = (imr1 - imr0)/sqrt(c) at U = sqrt(c) u       R/update_vb.R:217-234
+    // This wave shares its SIMD only with the recurrence wave, whose dependent chain leaves the VALU mostly idle.
+    double st_A[4], st_g[4], st_m[4], st_B[4], st_a[4], st_G[4], st_Gx[4];
+    const double zk = a.zeta[ktrait];
+    double th[4];   // theta of the block to be staged next, loaded a phase earlier so that the arithmetic never waits for HBM
+    auto theta_load = [&](int b) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) th[r] = a.theta[16 * b + hj0 + 4 * r];
+    };
+    auto stage_load = [&](int b) {   // memory part: issue the loads, no waiting
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int e = lane + 64 * r;
         size_t off = tbase + (size_t)(16 * b) * 16 + e;
-        st_A[r] = a.Aarr[off];
         st_g[r] = a.gam[off];
         st_m[r] = a.mu[off];
-        st_B[r] = a.Barr[off];
         st_G[r] = a.G[(size_t)b * 256 + e];
         st_Gx[r] = a.Gx[(size_t)b * 256 + e];
+      }
+    };
+    auto stage_probit = [&](int b) {   // arithmetic part, from th[] (block b)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int j = 16 * b + hj0 + 4 * r;
+        const double u = th[r] + zk;
+        double A, imr1, imr0, ee;
+        aq_probit_A_imr(u, &A, &imr1, &imr0, &ee);
+        if (!a.c_is_one) {
+          double Ac;
+          aq_probit_A_imr(a.sqrt_c * u, &Ac, &imr1, &imr0, &ee);
+          imr1 /= a.sqrt_c;
+          imr0 /= a.sqrt_c;
+        }
+        const bool valid = kvalid && j < a.p;
+        st_A[r] = valid ? A : 0.0;
+        st_B[r] = valid ? imr1 - imr0 : 0.0;
+        st_a[r] = valid ? u + imr0 : 0.0;
       }
     };
     auto stage_commit = [&](int par) {
@@ -187,6 +216,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         LA[par][e] = st_A[r];
         Lm1[par][e] = st_g[r] * st_m[r];
         LB[par][e] = st_B[r];
+        Laa[par][e] = st_a[r];
         LG[par][hj * 32 + hk] = st_G[r];
         LGx[par][e] = st_Gx[r];
       }
@@ -203,7 +233,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         double gb = 0.0;
         if (kvalid && j < a.p) {
           double be = gm * mu;
-          gb = gm * LB[par][e];
+          gb = Laa[par][e] + gm * LB[par][e];       // Z_jk = a + gam b: its row and column sums are all that is needed
           Lred[0][e] += gm;
           Lred[1][e] += (mu * mu + sig2b_k) * gm;   // update_m2_beta_, R/update_vb.R:19-31
           Lred[2][e] += be * be;
@@ -235,7 +265,10 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         __syncthreads();
       }
     } else {
+      theta_load(seg_b0);
       stage_load(seg_b0);
+      stage_probit(seg_b0);
+      if (seg_b0 + 1 < seg_b1) theta_load(seg_b0 + 1);
       stage_commit(seg_b0 & 1);
       aq_lds_barrier();   // prologue
       for (int b = seg_b0; b < seg_b1; b++) {
@@ -243,6 +276,8 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         const bool more = (b + 1 < seg_b1);
         if (more) stage_load(b + 1);
         if (b > seg_b0) finalize(b - 1, par ^ 1);
+        if (more) stage_probit(b + 1);
+        if (b + 2 < seg_b1) theta_load(b + 2);
         if (more) stage_commit(par ^ 1);
         aq_lds_barrier();
       }

@@ -152,6 +152,7 @@ struct AqPrepass {
   int p, q, p_pad, q_pad, rows_per_chunk;
   double sqrt_c;
   int c_is_one, do_H;
+  int write_AB;   // 0: only the ELBO part (do_H); A, b and the sums of a are produced inside the sweep kernel
 };
 
 __global__ __launch_bounds__(256) void aq_k_prepass(AqPrepass v) {
@@ -189,19 +190,21 @@ __global__ __launch_bounds__(256) void aq_k_prepass(AqPrepass v) {
         hacc += g * lP + (1 - g) * l1 - g * log(g + eps) - (1 - g) * log(1 - g + eps);
       }
     }
-    v.Aarr[off] = A;
-    v.Barr[off] = B;
-    double r = aa;
-    r += __shfl_xor(r, 8, 64);
-    r += __shfl_xor(r, 4, 64);
-    r += __shfl_xor(r, 2, 64);
-    r += __shfl_xor(r, 1, 64);
-    if (hk == 0) v.rowA[(size_t)tile * v.p_pad + j] = r;
+    if (v.write_AB) {
+      v.Aarr[off] = A;
+      v.Barr[off] = B;
+      double r = aa;
+      r += __shfl_xor(r, 8, 64);
+      r += __shfl_xor(r, 4, 64);
+      r += __shfl_xor(r, 2, 64);
+      r += __shfl_xor(r, 1, 64);
+      if (hk == 0) v.rowA[(size_t)tile * v.p_pad + j] = r;
+    }
   }
   // column sums of a over the 16 row slots -> colApart[chunk][kk]
   sh[threadIdx.x] = colA;
   __syncthreads();
-  if (threadIdx.x < 16) {
+  if (threadIdx.x < 16 && v.write_AB) {
     double s = 0.0;
     for (int r = 0; r < 16; r++) s += sh[r * 16 + threadIdx.x];
     v.colApart[(size_t)chunk * v.q_pad + tile * 16 + threadIdx.x] = s;

@@ -155,6 +155,7 @@ struct aq_vb {
   hipStream_t gstream[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   bool pre_done = false;
+  bool fused = false;    // look-ahead kernel: the pre-pass (A, b, sums of a) is computed inside the sweep kernel
   double *red = nullptr, *ered = nullptr, *Hpart = nullptr;
   bool own_red = false, own_ered = false;
   AqScalars *sc = nullptr;
@@ -274,6 +275,8 @@ static int aq_launch_mis(aq_vb *s, int mode, double c) {
 static int aq_launch_core(aq_vb *s, int mode, double c) {
   AqCoreArgs a;
   a.XA = s->XA; a.XU = s->XU; a.G = s->G; a.Gx = s->Gx; a.R = s->R; a.gam = s->gam; a.mu = s->mu;
+  a.theta = s->theta; a.zeta = s->zeta; a.sqrt_c = std::sqrt(c);
+  a.c_is_one = std::fabs(c - 1.0) < 1.5e-8 ? 1 : 0;   // isTRUE(all.equal(c, 1)), R/update_vb.R:219
   a.Aarr = s->Aarr; a.Barr = s->Barr; a.coef = s->coef; a.inv2s = s->inv2s; a.cst = s->cst; a.sig2b = s->sig2b;
   a.sums = s->sums; a.rowGB = s->rowGB;
   a.c = c;
@@ -384,7 +387,7 @@ static AqQvec aq_qvec(aq_vb *s) {
   v.eta_h = s->eta_h; v.kappa_h = s->kappa_h; v.n0 = s->n0; v.nobs = s->nobs;
   v.zeta = s->zeta; v.tau = s->tau; v.sig2b = s->sig2b; v.log_tau = s->log_tau; v.eta_vb = s->eta_vb;
   v.kappa_vb = s->kappa_vb; v.coef = s->coef; v.inv2s = s->inv2s; v.cst = s->cst; v.sums = s->sums;
-  v.colApart = s->colApart; v.nchunk = s->nHchunk;
+  v.colApart = s->colApart; v.nchunk = s->fused ? 0 : s->nHchunk;   // fused: colSums(a) is already inside sums[3]
   v.q = s->q; v.q_pad = s->q_pad; v.n = s->n; v.nu_h = s->nu; v.rho_h = s->rho;
   v.na = s->has_missing ? 1 : 0;
   return v;
@@ -613,8 +616,11 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   if (s->ngroup > 1) AQ_HIPF(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   AQ_TRYF(aq_dalloc(&s->rowA, (size_t)s->ntile * s->p_pad));
   AQ_TRYF(aq_dalloc(&s->rowGB, (size_t)s->ntile * s->WPT * s->p_pad));
-  AQ_TRYF(aq_dalloc(&s->Aarr, (size_t)s->ntile * s->p_pad * 16));
-  AQ_TRYF(aq_dalloc(&s->Barr, (size_t)s->ntile * s->p_pad * 16));
+  s->fused = s->use_la;
+  if (!s->fused) {   // the other kernels read A and b from the pre-pass arrays
+    AQ_TRYF(aq_dalloc(&s->Aarr, (size_t)s->ntile * s->p_pad * 16));
+    AQ_TRYF(aq_dalloc(&s->Barr, (size_t)s->ntile * s->p_pad * 16));
+  }
   if (pr->ext_reduce_main) { s->red = pr->ext_reduce_main; s->own_red = false; }
   else { AQ_TRYF(aq_dalloc(&s->red, (size_t)aq_vb_reduce_len(s->p))); s->own_red = true; }
   if (pr->ext_reduce_elbo) { s->ered = pr->ext_reduce_elbo; s->own_ered = false; }
@@ -745,6 +751,7 @@ static int aq_launch_prepass(aq_vb *s, double c, int do_H) {
   v.rows_per_chunk = s->rows_per_chunk; v.sqrt_c = std::sqrt(c);
   v.c_is_one = std::fabs(c - 1.0) < 1.5e-8 ? 1 : 0;   // isTRUE(all.equal(c, 1)), R/update_vb.R:219
   v.do_H = do_H;
+  v.write_AB = s->fused ? 0 : 1;
   hipLaunchKernelGGL(aq_k_prepass, dim3(s->nHchunk, s->ntile), dim3(256), 0, 0, v);
   AQ_HIP(hipGetLastError());
   return AQ_OK;
@@ -752,7 +759,7 @@ static int aq_launch_prepass(aq_vb *s, double c, int do_H) {
 
 static int aq_sweep_part_a(aq_vb *s) {
   AqQvec qv = aq_qvec(s);
-  if (!s->pre_done) AQ_TRY(aq_launch_prepass(s, s->c, 0));
+  if (!s->pre_done && !s->fused) AQ_TRY(aq_launch_prepass(s, s->c, 0));
   s->pre_done = false;
   hipLaunchKernelGGL(aq_k_qpre, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, qv, s->sc, s->c);
   AQ_TRY(aq_launch_core(s, 0, s->c));
@@ -782,7 +789,7 @@ static int aq_elbo_local(aq_vb *s) {
   AqPvec pv = aq_pvec(s);
   // the pre-pass of the NEXT sweep (same refreshed theta + zeta, c = 1 here) also yields the p x q ELBO part
   AQ_TRY(aq_launch_prepass(s, s->c, 1));
-  s->pre_done = true;
+  s->pre_done = !s->fused;
   hipLaunchKernelGGL(aq_k_elbo_C, dim3(1), dim3(1024), 0, 0, pv, s->sc);
   hipLaunchKernelGGL(aq_k_elbo_q, dim3(1), dim3(1024), 0, 0, qv, s->sc, s->Hpart, s->ntile * s->nHchunk, s->ered);
   AQ_HIP(hipGetLastError());
