@@ -32,9 +32,6 @@
 #ifndef AQ_DIAG
 #define AQ_DIAG 0      // timing diagnostics only (wrong results): 1 = skip the sequential pass, 2 = skip the MFMAs
 #endif
-#ifndef AQ_USE_DMA
-#define AQ_USE_DMA 0   // operand stream through an LDS-DMA ring (1) or register prefetch one tile ahead (0)
-#endif
 
 typedef double aq_d4 __attribute__((ext_vector_type(4)));
 
@@ -46,8 +43,8 @@ struct AqCoreArgs {
   double *R;          // [ntile][n_pad][16]
   double *gam;        // [ntile][p_pad][16]
   double *mu;         // [ntile][p_pad][16]
-  const double *Aarr;    // [ntile][p_pad][16]  log(1-Phi) - log Phi of theta_j + zeta_k   (pre-pass)
-  const double *Barr;    // [ntile][p_pad][16]  slope of Z in gam                          (pre-pass)
+  const double *Aarr;    // [ntile][p_pad][16]  log(1-Phi) - log Phi of theta_j + zeta_k   (pre-pass; not read by the look-ahead kernel)
+  const double *Barr;    // [ntile][p_pad][16]  slope of Z in gam                          (pre-pass; not read by the look-ahead kernel)
   const double *coef;    // [q_pad]  c*sig2_beta*tau
   const double *inv2s;   // [q_pad]  1/(2 sig2_beta)
   const double *cst;     // [q_pad]  -(log_tau + log_sig2_inv + log sig2_beta)/2
@@ -69,8 +66,6 @@ struct AqCoreArgs {
   const double *zeta;
   double sqrt_c;         // annealing: the Mills ratios are taken at sqrt(c) (theta_j + zeta_k), R/update_vb.R:219-224
   int c_is_one;
-  int wt_base[16];       // look-ahead kernel: first residual tile of each matrix wave ...
-  int wt_cnt[16];        // ... and how many it owns (uneven: the wave sharing a SIMD with the recurrence wave gets fewer)
 };
 
 __device__ __forceinline__ aq_d4 aq_mfma(double a, double b, aq_d4 c) {
@@ -79,30 +74,6 @@ __device__ __forceinline__ aq_d4 aq_mfma(double a, double b, aq_d4 c) {
 // Workgroup barrier that waits for this wave's LDS traffic only: global loads issued before it
 // (operand prefetch, staging) stay in flight across it.  __syncthreads() would drain vmcnt too.
 __device__ __forceinline__ void aq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at a
-// wave-uniform base (global_load_lds_dwordx4); no VGPR destination, counted in vmcnt.
-__device__ __forceinline__ void aq_dma16(const double2 *gsrc, double2 *ldst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                   (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
-}
-// 16-byte LDS read the compiler cannot see (it would otherwise drain vmcnt before any LDS read
-// while LDS-DMA pieces are pending).  The caller waits lgkmcnt(0) before using the value.
-__device__ __forceinline__ double2 aq_lds_read16_raw(const double2 *p) {
-  double2 v;
-  unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) double2 *)p;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-// wait until at most `groups` DMA groups (4 pieces each) issued after the one needed are outstanding;
-// the argument folds to a constant in the unrolled tile loop
-__device__ __forceinline__ void aq_wait_vm_groups(int groups) {
-  switch (groups) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-  }
-}
 __device__ __forceinline__ int aq_drow(int dmode, int reg, int g) { return (dmode ? 1 : 4) * reg + (dmode ? 4 : 1) * g; }
 
 // NT: 16-sample residual tiles per wave; NW: waves per workgroup; TT: 16-trait tiles per workgroup.
@@ -127,10 +98,6 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
   __shared__ double Lred[4][TT][256];   // per-thread running column sums (gam, m2, beta^2, gam*b)
   __shared__ double LB[TT][256];        // slope b of Z for the block
   __shared__ double Lrn[NW * 4][TT][16];
-  // per-wave operand ring, D slots of one residual-tile step: [XU h0, XU h1, XA h0, XA h1] x 64 lanes x 16 B
-  // (TT == 1 runs two workgroups per CU: 3 slots keep two of them inside the 160 KiB of LDS)
-  constexpr int D = (NT < 4) ? 2 : (TT == 1 ? (NW == 4 ? 3 : 2) : 4);
-  __shared__ double2 Xring[AQ_USE_DMA ? NW : 1][AQ_USE_DMA ? D : 1][4][64];
 
   // ---- residual tiles into registers: Rr[tt][t][r] <-> sample 16*(w*NT+t) + drow(r,g), trait col
   aq_d4 Rr[TT][NT];
@@ -252,16 +219,6 @@ __global__ __launch_bounds__(NW * 64, (TT == 1 ? 2 : 1)) void aq_core_sweep_kern
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // operand stream: step (bb, t) = XU tile t of block bb (update) + XA tile t of block bb+1 (next S)
-    auto dma_step = [&](int bb, int t, int slot) {
-      const double2 *xu = XUw + ((size_t)bb * NTT + t) * 128;
-      const int bn = (bb + 1 < a.nb) ? bb + 1 : bb;
-      const double2 *xa = XAw + ((size_t)bn * NTT + t) * 128;
-      aq_dma16(xu, &Xring[w][slot][0][0]);
-      aq_dma16(xu + 64, &Xring[w][slot][1][0]);
-      aq_dma16(xa, &Xring[w][slot][2][0]);
-      aq_dma16(xa + 64, &Xring[w][slot][3][0]);
-    };
     if (helper) { stage_load(0); stage_commit(); }
 
     for (int b = 0; b < a.nb; b++) {

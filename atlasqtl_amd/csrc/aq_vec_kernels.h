@@ -289,9 +289,8 @@ __global__ void aq_k_reduce_rows(const double *__restrict__ rowA, const double *
   red[j] = s;
 }
 
-// sums[0] <- column sums added over the SNP-segment slots (fixed order).  Groups of trait tiles may leave
-// their last slot empty (zeroed); ||R||^2 is taken from the last slot that group actually used.
-__global__ void aq_k_combine_segment_sums(double *sums, int q_pad, int nslot, int ntile, int ngroup) {
+// sums[0] <- column sums added over the chained SNP-segment slots (fixed order); ||R||^2 is the last segment's.
+__global__ void aq_k_combine_segment_sums(double *sums, int q_pad, int nslot) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= q_pad) return;
   size_t Q = q_pad;
@@ -300,13 +299,7 @@ __global__ void aq_k_combine_segment_sums(double *sums, int q_pad, int nslot, in
     for (int s = 1; s < nslot; s++) acc += sums[(size_t)s * 5 * Q + v * Q + k];
     sums[v * Q + k] = acc;
   }
-  // group of this trait's tile: group 0 ends in slot nslot-2 (its boundaries are unshifted), the others in nslot-1
-  int tile = k / 16, gi = 0;
-  for (int g2 = 0; g2 < ngroup; g2++)
-    if (tile >= (int)((long long)ntile * g2 / ngroup)) gi = g2;
-  int last = (gi == 0) ? nslot - 2 : nslot - 1;
-  if (last < 0) last = 0;
-  sums[4 * Q + k] = sums[(size_t)last * 5 * Q + 4 * Q + k];
+  sums[4 * Q + k] = sums[(size_t)(nslot - 1) * 5 * Q + 4 * Q + k];
 }
 
 __device__ __forceinline__ double aq_block_sum_1024(double v, double *sh) {

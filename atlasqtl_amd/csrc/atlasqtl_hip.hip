@@ -149,11 +149,8 @@ struct aq_vb {
   int *pflag = nullptr;
   double *Xcm = nullptr, *mis = nullptr, *XN = nullptr;
   int ncu = 256;
-  int nseg = 1, ngroup = 1; // SNP segments x trait-tile groups (streams) of the full-sweep launches
   int chain = 0;            // > 1: chained-segment launch with that many SNP segments (aq_core_sweep_la.h, SEG)
   int *done = nullptr, *errflag = nullptr;
-  hipStream_t gstream[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   bool pre_done = false;
   bool fused = false;    // look-ahead kernel: the pre-pass (A, b, sums of a) is computed inside the sweep kernel
   double *red = nullptr, *ered = nullptr, *Hpart = nullptr;
@@ -195,11 +192,6 @@ static void aq_free_all(aq_vb *s) {
     hipEventDestroy(e.first);
     hipEventDestroy(e.second);
   }
-  for (int gi = 0; gi < 4; gi++) {
-    if (s->gstream[gi]) hipStreamDestroy(s->gstream[gi]);
-    if (s->ev_join[gi]) hipEventDestroy(s->ev_join[gi]);
-  }
-  if (s->ev_fork) hipEventDestroy(s->ev_fork);
   if (s->done) hipFree(s->done);
   if (s->errflag) hipFree(s->errflag);
   delete s;
@@ -328,38 +320,9 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
         return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
       }
 #undef AQ_LAC
-      AQ_HIP(hipMemsetAsync(s->sums + (size_t)s->chain * 5 * s->q_pad, 0, (size_t)5 * s->q_pad * sizeof(double), 0));
-      hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad,
-                         s->chain + 1, s->ntile, 1);
-    } else if (mode == 1 || (s->nseg <= 1 && s->ngroup <= 1)) {
-      AQ_TRY(launch(0, s->ntile, 0, s->nb, 0, 0));
+      hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
     } else {
-      const int G = s->ngroup, S = s->nseg;
-      if (G > 1) AQ_HIP(hipEventRecord(s->ev_fork, 0));
-      for (int gi = 0; gi < G; gi++) {
-        hipStream_t st = G > 1 ? s->gstream[gi] : (hipStream_t)0;
-        if (G > 1) AQ_HIP(hipStreamWaitEvent(st, s->ev_fork, 0));
-        const int t_lo = (int)((long long)s->ntile * gi / G), t_hi = (int)((long long)s->ntile * (gi + 1) / G);
-        // group gi's boundaries are shifted by gi/G of a segment: S + 1 launches, the first and last shorter
-        int prev = 0;
-        for (int sg = 0; sg <= S; sg++) {
-          long long num = (long long)s->nb * ((long long)(sg + 1) * G - gi);
-          int b1 = sg == S ? s->nb : (int)(num / ((long long)S * G));
-          if (b1 > s->nb) b1 = s->nb;
-          if (b1 > prev) AQ_TRY(launch(t_lo, t_hi, prev, b1, sg, st));
-          else {
-            for (int v = 0; v < 5; v++)   // empty slot, this group's traits only (other groups write theirs concurrently)
-              AQ_HIP(hipMemsetAsync(s->sums + ((size_t)sg * 5 + v) * s->q_pad + (size_t)t_lo * 16, 0,
-                                    (size_t)(t_hi - t_lo) * 16 * sizeof(double), st));
-          }
-          prev = b1;
-        }
-        if (G > 1) {
-          AQ_HIP(hipEventRecord(s->ev_join[gi], st));
-          AQ_HIP(hipStreamWaitEvent(0, s->ev_join[gi], 0));
-        }
-      }
-      hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, S + 1, s->ntile, G);
+      AQ_TRY(launch(0, s->ntile, 0, s->nb, 0, 0));
     }
   } else
 #define AQ_CASE(NT_, NW_, TT_)                                                             \
@@ -508,12 +471,6 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       if (s->NT2 < 1) s->NT2 = s->NT;
       if (s->NT > 11) { s->use_la = false; s->NT = 16; s->NW = 4; }   // falls back to the two-barrier kernel
       else s->n_pad = 16 * 3 * (s->NT + s->NT2);
-      // More trait tiles than CUs (one workgroup per CU): the last round of workgroups leaves CUs idle.  Cut the
-      // SNP axis into segments and the tiles into stream groups whose segment boundaries are staggered, so that
-      // one group's partial last round overlaps another group's full rounds; stream order keeps segment s of a
-      // tile behind its segment s-1 (each segment starts from a complete residual).
-      // (measured on MI355X: no gain over a single launch -- the chip is power/clock limited when every CU issues
-      //  f64 MFMAs, and a partial last round runs correspondingly faster -- so this stays off unless requested)
       // more trait tiles than CUs: chained SNP segments even out the last round (3 rounds -> ~2.5 for 625 tiles)
       if (s->ntile > s->ncu) {
         double best = 1e30;
@@ -527,10 +484,6 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       if (const char *e = getenv("AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
       if (s->chain > s->nb) s->chain = s->nb;
       if (s->chain > 32) s->chain = 32;
-      if (const char *e = getenv("AQ_NSEG")) s->nseg = atoi(e) > 0 ? atoi(e) : 1;
-      if (const char *e = getenv("AQ_NGROUP")) s->ngroup = atoi(e) > 0 && atoi(e) <= 4 ? atoi(e) : 1;
-      if (s->nseg > s->nb) s->nseg = s->nb;
-      if (s->nseg > 16) s->nseg = 16;
     }
   }
   if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
@@ -604,16 +557,9 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   double **qv[] = {&s->eta_h, &s->kappa_h, &s->n0, &s->nobs, &s->zeta, &s->tau, &s->sig2b, &s->log_tau, &s->eta_vb,
                    &s->kappa_vb, &s->coef, &s->inv2s, &s->cst};
   for (double **qp : qv) AQ_TRYF(aq_dalloc(qp, (size_t)s->q_pad));
-  AQ_TRYF(aq_dalloc(&s->sums, (size_t)5 * s->q_pad * ((s->nseg > s->chain ? s->nseg : s->chain) + 2)));
+  AQ_TRYF(aq_dalloc(&s->sums, (size_t)5 * s->q_pad * (s->chain + 2)));   // one slot of 5 rows per chained segment (>= the 6 rows of the NA forms)
   AQ_TRYF(aq_dalloc(&s->done, (size_t)s->ntile));
   AQ_TRYF(aq_dalloc(&s->errflag, (size_t)1));
-  for (int gi = 0; gi < s->ngroup && s->ngroup > 1; gi++) {
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);            // lo = lowest priority (numerically greatest)
-    AQ_HIPF(hipStreamCreateWithPriority(&s->gstream[gi], hipStreamNonBlocking, gi == 0 ? hi : lo));
-    AQ_HIPF(hipEventCreateWithFlags(&s->ev_join[gi], hipEventDisableTiming));
-  }
-  if (s->ngroup > 1) AQ_HIPF(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   AQ_TRYF(aq_dalloc(&s->rowA, (size_t)s->ntile * s->p_pad));
   AQ_TRYF(aq_dalloc(&s->rowGB, (size_t)s->ntile * s->WPT * s->p_pad));
   s->fused = s->use_la;
