@@ -65,6 +65,10 @@ SYMBOLS = {
     "aq_vb_get_status": (C.c_int, [C.c_void_p, C.POINTER(AqVbStatus)]),
     "aq_vb_get_elbo_trace": (C.c_int32, [C.c_void_p, ip, dp, C.c_int32]),
     "aq_vb_get_result": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
+    "aq_assign_bfdr": (C.c_int, [dp, dp, C.c_int64, C.c_int32]),
+    "aq_hotspot_sizes": (C.c_int, [dp, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64), C.c_int32]),
+    "aq_vb_hotspot_sizes": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "aq_vb_state_bytes": (C.c_int64, [C.c_void_p]),
     "aq_vb_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "aq_vb_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

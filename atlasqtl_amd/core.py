@@ -232,6 +232,14 @@ class VbRun:
         self.advance_until_done()
         check(lib().aq_vb_set_sweep_budget(self.h, -1), "aq_vb_set_sweep_budget")
 
+    def hotspot_sizes(self, thres=0.5, fdr_adjust=False):
+        """Hotspot sizes from the gam_vb resident on the device (no p x q copy to the host)."""
+        rs = np.zeros(self.p, dtype=np.int64)
+        tot = C.c_int64(0)
+        check(lib().aq_vb_hotspot_sizes(self.h, float(thres), int(bool(fdr_adjust)), rs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        C.byref(tot)), "aq_vb_hotspot_sizes")
+        return rs, int(tot.value)
+
     def get_state(self):
         """The complete loop state between two sweeps as one uint8 array (aq_vb_get_state): unlike the reference's
         write-only checkpoint_ (R/utils.R:571-611), `set_state` on a handle created for the same problem continues
@@ -279,6 +287,27 @@ class VbRun:
         if full_output:
             out.update(mu_beta_vb=mu, lam2_inv_vb=lam, sig2_theta_vb=s2t, tau_vb=tau, sig2_beta_vb=s2b)
         return out
+
+
+def assign_bFDR(mat_ppi, device=0):
+    """assign_bFDR of the reference (R/summarise_output.R:207-223) on the GPU: sort of all p q PPIs (hipCUB radix sort,
+    ties in original order), running mean of 1 - PPI, scattered back."""
+    m = np.asarray(mat_ppi, dtype=np.float64)
+    vec = np.ascontiguousarray(m.reshape(-1, order="F"))
+    out = np.empty_like(vec)
+    check(lib().aq_assign_bfdr(as_dp(vec), as_dp(out), vec.size, int(device)), "aq_assign_bfdr")
+    return out.reshape(m.shape, order="F")
+
+
+def hotspot_sizes(gam_vb, thres=0.5, fdr_adjust=False, device=0):
+    """rs_thres and nb_pairwise of summary.atlasqtl / plot.atlasqtl (R/summarise_output.R:98-105,177-182)."""
+    m = np.asfortranarray(gam_vb, dtype=np.float64)
+    p, q = m.shape
+    rs = np.zeros(p, dtype=np.int64)
+    tot = C.c_int64(0)
+    check(lib().aq_hotspot_sizes(as_dp(m), p, q, float(thres), int(bool(fdr_adjust)),
+                                 rs.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(tot), int(device)), "aq_hotspot_sizes")
+    return rs, int(tot.value)
 
 
 def _run_with_checkpoints(run, checkpoint_path, rate, maxit):

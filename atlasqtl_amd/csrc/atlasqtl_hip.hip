@@ -27,6 +27,10 @@ static int aq_fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
 }
+int aq_fail_ext(int code, const std::string &msg) { return aq_fail(code, msg); }   // for aq_postproc.hip
+// aq_postproc.hip (hipCUB sort / scan)
+int aq_bfdr_device(const double *d_ppi, double *d_fdr, int64_t len);
+int aq_row_count_device(const double *d_m, int64_t *d_rs, int p, int q, double thres, int lt);
 #define AQ_HIP(call)                                                                                   \
   do {                                                                                                 \
     hipError_t e_ = (call);                                                                            \
@@ -893,6 +897,76 @@ static void aq_resolve_events(aq_vb *s) {
     hipEventDestroy(e.second);
   }
   s->ev.clear();
+}
+
+// ------------------------------------------------------------ post-processing ----
+extern "C" int aq_assign_bfdr(const double *mat_ppi, double *mat_fdr, int64_t len, int32_t device) {
+  if (!mat_ppi || !mat_fdr || len < 0) return aq_fail(AQ_ERR_ARG, "aq_assign_bfdr: bad argument");
+  AQ_TRY(aq_need_device(device));
+  if (len == 0) return AQ_OK;
+  double *din = nullptr, *dout = nullptr;
+  AQ_HIP(hipMalloc((void **)&din, (size_t)len * sizeof(double)));
+  AQ_HIP(hipMalloc((void **)&dout, (size_t)len * sizeof(double)));
+  AQ_HIP(hipMemcpy(din, mat_ppi, (size_t)len * sizeof(double), hipMemcpyHostToDevice));
+  int rc = aq_bfdr_device(din, dout, len);
+  if (rc == AQ_OK && hipMemcpy(mat_fdr, dout, (size_t)len * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    rc = aq_fail(AQ_ERR_DEVICE, "aq_assign_bfdr: copy back failed");
+  hipFree(din);
+  hipFree(dout);
+  return rc;
+}
+
+// d_m: p x q column-major PPIs on the device (overwritten by the FDR matrix when fdr_adjust)
+static int aq_hotspot_common(double *d_m, int p, int q, double thres, int fdr_adjust, int64_t *rs_thres, int64_t *nb_pairwise) {
+  int lt = 0;
+  if (fdr_adjust) {
+    double *d_f = nullptr;
+    AQ_HIP(hipMalloc((void **)&d_f, (size_t)p * q * sizeof(double)));
+    int rc = aq_bfdr_device(d_m, d_f, (int64_t)p * q);
+    if (rc == AQ_OK) {
+      hipError_t e = hipMemcpy(d_m, d_f, (size_t)p * q * sizeof(double), hipMemcpyDeviceToDevice);
+      if (e != hipSuccess) rc = aq_fail(AQ_ERR_DEVICE, "aq_hotspot_sizes: device copy failed");
+    }
+    hipFree(d_f);
+    if (rc != AQ_OK) return rc;
+    lt = 1;                                                      // rowSums(mat_fdr < thres), R/summarise_output.R:100
+  }
+  int64_t *d_rs = nullptr;
+  AQ_HIP(hipMalloc((void **)&d_rs, (size_t)p * sizeof(int64_t)));
+  int rc = aq_row_count_device(d_m, d_rs, p, q, thres, lt);    // rowSums(gam_vb > thres), :103
+  std::vector<int64_t> rs(p);
+  if (rc == AQ_OK && hipMemcpy(rs.data(), d_rs, (size_t)p * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)
+    rc = aq_fail(AQ_ERR_DEVICE, "aq_hotspot_sizes: copy back failed");
+  hipFree(d_rs);
+  if (rc != AQ_OK) return rc;
+  int64_t tot = 0;
+  for (int j = 0; j < p; j++) { tot += rs[j]; if (rs_thres) rs_thres[j] = rs[j]; }
+  if (nb_pairwise) *nb_pairwise = tot;                           // sum(gam_vb > thres), :102
+  return AQ_OK;
+}
+
+extern "C" int aq_hotspot_sizes(const double *mat_ppi, int32_t p, int32_t q, double thres, int32_t fdr_adjust,
+                                int64_t *rs_thres, int64_t *nb_pairwise, int32_t device) {
+  if (!mat_ppi || p <= 0 || q <= 0) return aq_fail(AQ_ERR_ARG, "aq_hotspot_sizes: bad argument");
+  AQ_TRY(aq_need_device(device));
+  double *d_m = nullptr;
+  AQ_HIP(hipMalloc((void **)&d_m, (size_t)p * q * sizeof(double)));
+  AQ_HIP(hipMemcpy(d_m, mat_ppi, (size_t)p * q * sizeof(double), hipMemcpyHostToDevice));
+  int rc = aq_hotspot_common(d_m, p, q, thres, fdr_adjust, rs_thres, nb_pairwise);
+  hipFree(d_m);
+  return rc;
+}
+
+extern "C" int aq_vb_hotspot_sizes(aq_vb_handle s, double thres, int32_t fdr_adjust, int64_t *rs_thres, int64_t *nb_pairwise) {
+  if (!s) return aq_fail(AQ_ERR_ARG, "NULL handle");
+  AQ_HIP(hipSetDevice(s->device));
+  double *d_m = nullptr;
+  AQ_HIP(hipMalloc((void **)&d_m, (size_t)s->p * s->q * sizeof(double)));
+  hipLaunchKernelGGL(aq_k_colmajor_from_tile, dim3((s->p_pad + 63) / 64, s->ntile), dim3(256), 0, 0, s->gam, (const double *)nullptr,
+                     d_m, s->p, s->q, s->p_pad);
+  int rc = aq_hotspot_common(d_m, s->p, s->q, thres, fdr_adjust, rs_thres, nb_pairwise);
+  hipFree(d_m);
+  return rc;
 }
 
 // ------------------------------------------------------ checkpoint / resume ----

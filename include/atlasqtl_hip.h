@@ -167,6 +167,21 @@ int aq_vb_get_result(aq_vb_handle h, double *beta_vb, double *gam_vb, double *mu
                      double *sig2_beta_vb);
 
 /* ------------------------------------------------------------------------------------------
+ * Post-processing of the posterior inclusion probabilities on the device.
+ *   aq_assign_bfdr       assign_bFDR, R/summarise_output.R:207-223: Bayesian FDR estimate of every entry of
+ *                        mat_ppi (len = p*q, any layout: the function works on as.vector(mat_ppi)); ties keep their
+ *                        original order as with R's order(decreasing = TRUE).  Host pointers.
+ *   aq_hotspot_sizes     rowSums(gam_vb > thres) / rowSums(assign_bFDR(gam_vb) < thres) and their total
+ *                        (summary.atlasqtl / plot.atlasqtl, R/summarise_output.R:98-105,177-182); mat_ppi p x q
+ *                        column-major on the host.
+ *   aq_vb_hotspot_sizes  the same from the gam_vb resident in a handle, without copying it to the host.
+ * ---------------------------------------------------------------------------------------- */
+int aq_assign_bfdr(const double *mat_ppi, double *mat_fdr, int64_t len, int32_t device);
+int aq_hotspot_sizes(const double *mat_ppi, int32_t p, int32_t q, double thres, int32_t fdr_adjust,
+                     int64_t *rs_thres, int64_t *nb_pairwise, int32_t device);
+int aq_vb_hotspot_sizes(aq_vb_handle h, double thres, int32_t fdr_adjust, int64_t *rs_thres, int64_t *nb_pairwise);
+
+/* ------------------------------------------------------------------------------------------
  * Checkpoint / resume.  The reference's checkpoint_ (R/utils.R:571-611, called at
  * R/atlasqtl_global_local_core.R:379) only writes outputs every 100 iterations and cannot resume; these
  * entries capture and restore the COMPLETE loop state between two sweeps (valid after aq_vb_run /

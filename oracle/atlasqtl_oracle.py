@@ -608,3 +608,28 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_
                    nu_s0_vb=float(nu_s0_vb), rho_s0_vb=float(rho_s0_vb), xi_inv_vb=float(xi_inv_vb),
                    L_vb=L_vb, cp_X_Xbeta=np.array(cp_X_Xbeta))
     return out
+
+
+# ----------------------------------------------------------------------------
+# post-processing
+# ----------------------------------------------------------------------------
+def assign_bFDR(mat_ppi):
+    """R/summarise_output.R:207-223: Bayesian FDR estimates from posterior probabilities of association.
+    order(vec_ppi, decreasing = TRUE) keeps ties in their original order (R's radix ordering is stable)."""
+    mat_ppi = np.asarray(mat_ppi, dtype=np.float64)
+    vec_ppi = mat_ppi.reshape(-1, order="F")                     # as.vector(mat_ppi)
+    ind = np.argsort(-vec_ppi, kind="stable")                    # :210
+    vec_ppi_ord = vec_ppi[ind]                                   # :211
+    vec_fdr_ord = np.cumsum(1 - vec_ppi_ord) / np.arange(1, vec_ppi.size + 1)   # :213
+    vec_fdr = np.empty_like(vec_fdr_ord)
+    vec_fdr[ind] = vec_fdr_ord                                   # :215-216 (vec_fdr_ord[order(ind)])
+    return vec_fdr.reshape(mat_ppi.shape, order="F")             # :218
+
+
+def hotspot_sizes(gam_vb, thres, fdr_adjust=False):
+    """summary.atlasqtl / plot.atlasqtl, R/summarise_output.R:98-105,177-182: (rs_thres, nb_pairwise)."""
+    if fdr_adjust:
+        m = assign_bFDR(gam_vb) < thres
+    else:
+        m = np.asarray(gam_vb) > thres
+    return m.sum(axis=1).astype(np.int64), int(m.sum())

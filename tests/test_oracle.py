@@ -133,3 +133,19 @@ def test_sharded_model_matches_driver_single_rank():
         np.testing.assert_allclose(lb, la, rtol=1e-10)
         np.testing.assert_allclose(b["mu_beta_vb"], a["mu_beta_vb"], rtol=1e-7, atol=1e-11)
         np.testing.assert_allclose(b["theta_vb"], a["theta_vb"], rtol=1e-8, atol=1e-11)
+
+
+def test_assign_bfdr_restatement_properties():
+    """R/summarise_output.R:207-223: the FDR of the top-ranked pair is 1 - its PPI, the values are non-decreasing along the
+    ranking, and the last one is the mean of 1 - PPI."""
+    from oracle import atlasqtl_oracle as O
+    rng = np.random.default_rng(1)
+    m = rng.beta(0.1, 1.0, size=(40, 9))
+    f = O.assign_bFDR(m)
+    v, fv = m.reshape(-1, order="F"), f.reshape(-1, order="F")
+    order = np.argsort(-v, kind="stable")
+    assert np.isclose(fv[order[0]], 1 - v[order[0]])
+    assert np.all(np.diff(fv[order]) >= -1e-15)
+    assert np.isclose(fv[order[-1]], np.mean(1 - v))
+    rs, nb = O.hotspot_sizes(m, 0.5)
+    assert nb == int((m > 0.5).sum()) and rs.shape == (40,)
