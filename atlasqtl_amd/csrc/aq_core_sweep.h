@@ -30,7 +30,7 @@
 #include "aq_special.h"
 
 #ifndef AQ_DIAG
-#define AQ_DIAG 0      // timing diagnostics only (wrong results): 1 = skip the sequential pass, 2 = skip the MFMAs
+#define AQ_DIAG 0      // timing diagnostics only (wrong results): 1 = skip the sequential pass, 2 = skip the MFMAs, 4 = no probit math in the helper wave, 8 = record per-phase time stamps of workgroup 0 into AqCoreArgs::dbg
 #endif
 
 typedef double aq_d4 __attribute__((ext_vector_type(4)));
@@ -62,6 +62,7 @@ struct AqCoreArgs {
   int nseg;              // > 1: chained-segment launch, block s*ntile + k = SNP segment s of trait tile k
   int *done;             // chained segments: done[tile] = number of that tile's segments already finished
   int *errflag;          // set when a bounded wait on done[] expires (results invalid, reported to the host)
+  long long *dbg;        // AQ_DIAG & 8 only: per-phase s_memtime stamps of workgroup 0 (tools/dev_check.py phases)
   const double *theta;   // look-ahead kernel (fused pre-pass): theta_vb [p_pad], zeta_vb [q_pad] of this sweep
   const double *zeta;
   double sqrt_c;         // annealing: the Mills ratios are taken at sqrt(c) (theta_j + zeta_k), R/update_vb.R:219-224

@@ -97,6 +97,8 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 
   if (is_rec) {
     // =========================== recurrence wave ===========================================
+    // highest issue priority on its SIMD: the helper wave (same SIMD) only gets the slots the dependent chain leaves free
+    __builtin_amdgcn_s_setprio(3);
     if (a.mode == 1) {
       for (int b = seg_b0; b < seg_b1; b++) {   // init mode: nothing to do, keep the barrier count
         __syncthreads();
@@ -111,6 +113,9 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       aq_lds_barrier();   // prologue
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
+#if AQ_DIAG & 8
+        const long long t_in = clock64();
+#endif
 #if !(AQ_DIAG & 1)
         // ---- SNP block b, lane = trait ---------------------------------------------------
         double S[16], dlp[16];
@@ -160,7 +165,16 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           m1o = m1o_n; cA = cA_n; dj = d_n;
         }
 #endif
+#if AQ_DIAG & 8
+        const long long t_work = clock64();
+#endif
         aq_lds_barrier();
+#if AQ_DIAG & 8
+        if (blockIdx.x == 0 && lane == 0 && a.dbg && (b - seg_b0) < 256) {
+          long long *d = a.dbg + ((size_t)(b - seg_b0) * 16 + w) * 3;
+          d[0] = t_in; d[1] = t_work; d[2] = clock64();
+        }
+#endif
       }
     }
     __syncthreads();   // matches the matrix waves' barrier before the final sums
@@ -196,7 +210,11 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         const int j = 16 * b + hj0 + 4 * r;
         const double u = th[r] + zk;
         double A, imr1, imr0, ee;
+#if AQ_DIAG & 4
+        A = u; imr1 = 1.0; imr0 = -1.0; ee = 0.0;        // timing diagnostics: no transcendental work in the helper wave
+#else
         aq_probit_A_imr(u, &A, &imr1, &imr0, &ee);
+#endif
         if (!a.c_is_one) {
           double Ac;
           aq_probit_A_imr(a.sqrt_c * u, &Ac, &imr1, &imr0, &ee);
@@ -274,12 +292,24 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
         const bool more = (b + 1 < seg_b1);
+#if AQ_DIAG & 8
+        const long long t_in = clock64();
+#endif
         if (more) stage_load(b + 1);
         if (b > seg_b0) finalize(b - 1, par ^ 1);
         if (more) stage_probit(b + 1);
         if (b + 2 < seg_b1) theta_load(b + 2);
         if (more) stage_commit(par ^ 1);
+#if AQ_DIAG & 8
+        const long long t_work = clock64();
+#endif
         aq_lds_barrier();
+#if AQ_DIAG & 8
+        if (blockIdx.x == 0 && lane == 0 && a.dbg && (b - seg_b0) < 256) {
+          long long *d = a.dbg + ((size_t)(b - seg_b0) * 16 + w) * 3;
+          d[0] = t_in; d[1] = t_work; d[2] = clock64();
+        }
+#endif
       }
       finalize(seg_b1 - 1, (seg_b1 - 1) & 1);
     }
@@ -300,7 +330,14 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     const double2 *XUw = a.XU + (size_t)my_t0 * 128 + lane;
 
     // matrix work of one phase: update with block bu (delta in LDS parity pu) and/or S' of block bs -> Sp[ps]
-    auto matrix_phase_n = [&](auto ntc, bool do_u, int bu, int pu, bool do_s, int bs, int ps) {
+    // operands of residual tile 0 of the NEXT phase, requested before the barrier so that no phase starts with an exposed load
+    double2 fu0, fu1, fa0, fa1;
+    auto prefetch_first = [&](int bu, bool do_s, int bs) {
+      const double2 *xu = XUw + (size_t)bu * NTT * 128;
+      const double2 *xa = XAw + (size_t)(do_s ? bs : 0) * NTT * 128;
+      fu0 = xu[0]; fu1 = xu[64]; fa0 = xa[0]; fa1 = xa[64];
+    };
+    auto matrix_phase_n = [&](auto ntc, bool do_u, int bu, int pu, bool do_s, int bs, int ps, bool pre) {
       constexpr int NTC = decltype(ntc)::value;
       double nd[4];
       if (do_u) {
@@ -310,7 +347,9 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       aq_d4 acc = {0, 0, 0, 0};
       const double2 *xu = XUw + (size_t)(do_u ? bu : 0) * NTT * 128;
       const double2 *xa = XAw + (size_t)(do_s ? bs : 0) * NTT * 128;
-      double2 cu0 = xu[0], cu1 = xu[64], ca0 = xa[0], ca1 = xa[64];
+      double2 cu0, cu1, ca0, ca1;
+      if (pre) { cu0 = fu0; cu1 = fu1; ca0 = fa0; ca1 = fa1; }   // tile 0 was requested before the previous barrier
+      else { cu0 = xu[0]; cu1 = xu[64]; ca0 = xa[0]; ca1 = xa[64]; }
 #pragma unroll
       for (int t = 0; t < NTC; t++) {
         double2 nu0, nu1, na0, na1;
@@ -340,36 +379,50 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         for (int i = 0; i < 4; i++) Sp[ps][mw][(mr * i + mg * g) * 16 + col] = acc[i];
       }
     };
-    auto matrix_phase = [&](bool do_u, int bu, int pu, bool do_s, int bs, int ps) {
-      if (NT2 == NT || hi) matrix_phase_n(std::integral_constant<int, NT>{}, do_u, bu, pu, do_s, bs, ps);
-      else matrix_phase_n(std::integral_constant<int, NT2>{}, do_u, bu, pu, do_s, bs, ps);
+    auto matrix_phase = [&](bool do_u, int bu, int pu, bool do_s, int bs, int ps, bool pre) {
+      if (NT2 == NT || hi) matrix_phase_n(std::integral_constant<int, NT>{}, do_u, bu, pu, do_s, bs, ps, pre);
+      else matrix_phase_n(std::integral_constant<int, NT2>{}, do_u, bu, pu, do_s, bs, ps, pre);
     };
 
     if (a.mode == 1) {
       // ---------------- init mode: R = Y - X (gam*mu), block by block; column sums of the initial state
       for (int b = seg_b0; b < seg_b1; b++) {
         __syncthreads();                                  // the helper wave has put beta of block b into Ldel[0]
-        matrix_phase(true, b, 0, false, 0, 0);
+        matrix_phase(true, b, 0, false, 0, 0, false);
         __syncthreads();
       }
     } else {
       // ---------------- full sweep -----------------------------------------------------
       // prologue: S'_0 from the untouched residual, staging of block 0
-      matrix_phase(false, 0, 0, true, seg_b0, seg_b0 & 1);
+      matrix_phase(false, 0, 0, true, seg_b0, seg_b0 & 1, false);
+      prefetch_first(0, seg_b0 + 1 < seg_b1, seg_b0 + 1);   // first phase: no update yet, S' of block seg_b0 + 1
       aq_lds_barrier();
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
         const bool more = (b + 1 < seg_b1);
         // update with block b-1, S' of block b+1
+#if AQ_DIAG & 8
+        const long long t_in = clock64();
+#endif
 #if !(AQ_DIAG & 2)
-        if (b > seg_b0 || more) matrix_phase(b > seg_b0, b - 1, par ^ 1, more, b + 1, par ^ 1);
+        if (b > seg_b0 || more) matrix_phase(b > seg_b0, b - 1, par ^ 1, more, b + 1, par ^ 1, true);
+        prefetch_first(b, b + 2 < seg_b1, b + 2);   // next phase (or the epilogue): update with block b, S' of block b + 2
+#endif
+#if AQ_DIAG & 8
+        const long long t_work = clock64();
 #endif
         aq_lds_barrier();
+#if AQ_DIAG & 8
+        if (blockIdx.x == 0 && lane == 0 && a.dbg && (b - seg_b0) < 256) {
+          long long *d = a.dbg + ((size_t)(b - seg_b0) * 16 + w) * 3;
+          d[0] = t_in; d[1] = t_work; d[2] = clock64();
+        }
+#endif
       }
       // epilogue: the last block's update and stores
       const int pl = (seg_b1 - 1) & 1;
 #if !(AQ_DIAG & 2)
-      matrix_phase(true, seg_b1 - 1, pl, false, 0, 0);
+      matrix_phase(true, seg_b1 - 1, pl, false, 0, 0, true);
 #endif
     }
     // ---- write the residual back and ||R_k||^2 partials ----

@@ -271,6 +271,12 @@ static int aq_launch_mis(aq_vb *s, int mode, double c) {
 static int aq_launch_core(aq_vb *s, int mode, double c) {
   AqCoreArgs a;
   a.XA = s->XA; a.XU = s->XU; a.G = s->G; a.Gx = s->Gx; a.R = s->R; a.gam = s->gam; a.mu = s->mu;
+  a.dbg = nullptr;
+#if AQ_DIAG & 8
+  static long long *dbg_buf = nullptr;
+  if (!dbg_buf) { AQ_HIP(hipMalloc((void **)&dbg_buf, 256 * 16 * 3 * sizeof(long long))); AQ_HIP(hipMemset(dbg_buf, 0, 256 * 16 * 3 * sizeof(long long))); }
+  a.dbg = dbg_buf;
+#endif
   a.theta = s->theta; a.zeta = s->zeta; a.sqrt_c = std::sqrt(c);
   a.c_is_one = std::fabs(c - 1.0) < 1.5e-8 ? 1 : 0;   // isTRUE(all.equal(c, 1)), R/update_vb.R:219
   a.Aarr = s->Aarr; a.Barr = s->Barr; a.coef = s->coef; a.inv2s = s->inv2s; a.cst = s->cst; a.sig2b = s->sig2b;
@@ -340,6 +346,19 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
 #undef AQ_CASE
   AQ_HIP(hipEventRecord(e1, 0));
   AQ_HIP(hipGetLastError());
+#if AQ_DIAG & 8
+  if (mode == 0 && getenv("AQ_DBG_DUMP") && s->it == 15) {
+    AQ_HIP(hipDeviceSynchronize());
+    std::vector<long long> h(256 * 16 * 3);
+    AQ_HIP(hipMemcpy(h.data(), a.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    FILE *f = fopen(getenv("AQ_DBG_DUMP"), "w");
+    if (f) {
+      for (int b = 0; b < 256; b++)
+        for (int w = 0; w < 8; w++) fprintf(f, "%d %d %lld %lld %lld\n", b, w, h[(b * 16 + w) * 3], h[(b * 16 + w) * 3 + 1], h[(b * 16 + w) * 3 + 2]);
+      fclose(f);
+    }
+  }
+#endif
   if (mode == 0) {
     s->ev.push_back({e0, e1});
   } else {
