@@ -117,46 +117,52 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         const long long t_in = clock64();
 #endif
 #if !(AQ_DIAG & 1)
-        // ---- SNP block b, lane = trait ---------------------------------------------------
-        double S[16], dlp[16];
+        // ---- SNP block b.  lane = (g, col): col = trait, g = lane >> 4 one of four row groups ----------------------
+        // This wave and the helper wave share one SIMD and both are bound by its fp64 VALU issue rate (a dependent
+        // v_fma_f64 has a latency of only 6 cycles, tools/microbench/f64_valu.hip), so everything that does not belong
+        // to the chain itself is spread over the four 16-lane groups instead of being repeated in each of them:
+        // group g owns the rows g, g+4, g+8, g+12 of S.
+        double Sown[4];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-          double s = Sp[par][0][j * 16 + col];
+        for (int r = 0; r < 4; r++) {
+          const int j = g + 4 * r;
+          double sv = Sp[par][0][j * 16 + col];
 #pragma unroll
-          for (int ww = 1; ww < NWM; ww++) s += Sp[par][ww][j * 16 + col];
-          S[j] = s;
-          dlp[j] = (b > seg_b0) ? Ldel[par ^ 1][j * 16 + col] : 0.0;   // delta of block b-1 (a segment starts from a complete residual)
+          for (int ww = 1; ww < NWM; ww++) sv += Sp[par][ww][j * 16 + col];
+          Sown[r] = sv;
         }
-        // cross-block correction of the first SNP; the others follow inside the loop, one row ahead
+        if (b > seg_b0) {
+          // cross-block correction X_b'X_{b-1} delta_{b-1} of this group's rows (a segment starts from a complete residual)
+          double dlp[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) S[0] -= LGx[par][i] * dlp[i];
+          for (int i = 0; i < 16; i++) dlp[i] = Ldel[par ^ 1][i * 16 + col];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const double *gx = &LGx[par][(g + 4 * r) * 16];
+            double cx = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) cx += gx[i] * dlp[i];
+            Sown[r] -= cx;
+          }
+        }
+        double sb = __shfl(Sown[0], col, 64);     // S of SNP 0 (group 0) to every group
         double m1o = Lm1[par][col], cA = a.c * (LA[par][col] + rc_cst), dj = LG[par][0];
-#pragma unroll 1
+#pragma unroll
         for (int j = 0; j < 16; j++) {
           const int jn = (j + 1) & 15;
           double m1o_n = Lm1[par][jn * 16 + col], cA_n = a.c * (LA[par][jn * 16 + col] + rc_cst), d_n = LG[par][jn * 33];
-          double s = S[0] + m1o * dj;                       // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1*cp_X(j,j))   :71
+          // the next SNP's S is fetched from its owner group BEFORE this step's delta is known (off the chain) ...
+          const double g_next = LG[par][j * 32 + jn];
+          const double s_next = __shfl(Sown[jn >> 2], (jn & 3) * 16 + col, 64);
+          double s = sb + m1o * dj;                         // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1*cp_X(j,j))   :71
           double mu = rc_coef * s;                          // :73
           double x = fma(-(s * s), rc_K, cA);               // c*(log(1-Phi) - log Phi - mu^2/(2 sig2) + cst), mu^2 = coef^2 s^2   :75-77
-          // cross-block correction of the NEXT SNP (row j+1 sits in S[1]); independent of the chain
-          {
-            double cx = 0.0;
-#pragma unroll
-            for (int i = 0; i < 16; i++) cx += LGx[par][jn * 16 + i] * dlp[i];
-            if (j < 15) S[1] -= cx;
-          }
           double gm = aq_sigmoid_neg_fast(x);
           double dl = gm * mu - m1o;                        // m1 - m1_old, m1 = gam*mu   :79
-          // in-block part of :81: S shifts down by one; G[j+1+i][j] reads the zero pad past the block
+          sb = s_next - g_next * dl;                        // ... and completed with this step's update: one FMA on the chain
+          // in-block part of :81, this group's rows (rows <= j are already consumed: updating them is harmless)
 #pragma unroll
-          for (int i0 = 0; i0 < 15; i0 += 8) {
-            double gc[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) gc[i] = (i0 + i < 15) ? LG[par][j * 32 + j + 1 + i0 + i] : 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-              if (i0 + i < 15) S[i0 + i] = S[i0 + i + 1] - gc[i] * dl;
-          }
+          for (int r = (j >> 2); r < 4; r++) Sown[r] -= LG[par][j * 32 + g + 4 * r] * dl;
           if (lane < 16) {
             Lgam[par][j * 16 + col] = gm;
             Lmu[par][j * 16 + col] = mu;
