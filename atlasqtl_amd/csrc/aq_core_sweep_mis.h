@@ -277,6 +277,57 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
           for (int r = 0; r < 4; r++) Sp[lane + 64 * r] = tot[r];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave reads it back below
         }
+        if (NT <= 8) {
+        // ---- sequential pass over the 16 SNPs (src/coreLoop.cpp:115-133).  lane = (g, col): col = trait, and the four
+        // 16-lane groups g share everything outside the dependency chain: group g owns rows 4g .. 4g+3 of S (as in
+        // aq_core_sweep_la.h; the in-block coupling uses the trait's own Gram block).  Rolled over the four owner groups
+        // so that the residual tiles this wave also holds stay in registers. ----
+        {
+          const double *Gk = LGk + buf * (256 * 17) + col;
+          double Sown[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int e = (4 * g + r) * 16 + col;
+            double sv = Sp[e];
+            if (a.C == 1) {
+#pragma unroll
+              for (int ww = 1; ww < NW; ww++) sv += Sp[ww * 256 + e];
+            }
+            Sown[r] = sv;
+          }
+          double sb = __shfl(Sown[0], col, 64);
+          double m1o = Lm1[col], cA = LcA[col], cf = Lcoef[col], ci = Lci2s[col], dj = Lxn[col];
+#pragma unroll 1
+          for (int q4 = 0; q4 < 4; q4++) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+              const int j = 4 * q4 + jj;
+              const int jn = (j + 1) & 15;
+              const int en = jn * 16 + col;
+              double m1o_n = Lm1[en], cA_n = LcA[en], cf_n = Lcoef[en], ci_n = Lci2s[en], d_n = Lxn[en];
+              const double g_next = Gk[(jn * 16 + j) * 17];
+              // the next SNP's S from its owner group, fetched ahead of the chain (owner q4, slot jj+1; or the next group's slot 0)
+              const double s_next = __shfl(Sown[(jj + 1) & 3], (jn >> 2) * 16 + col, 64);
+              double s = sb + m1o * dj;                         // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1 (cp_X - cp_X_rm_k)(j,j))   :121
+              double mu = cf * s;                               // :125
+              double x = fma(-(s * s), ci, cA);                 // :127-129 with mu^2 = coef^2 s^2 (keeps mu off the chain)
+              double gm = aq_sigmoid_neg_fast(x);
+              double dl = gm * mu - m1o;                        // m1 - m1_old   :130
+              sb = s_next - g_next * dl;
+              // in-block part of :132 with the trait's own Gram block, this group's rows (rows <= j are already consumed)
+#pragma unroll
+              for (int r = 0; r < 4; r++) Sown[r] -= Gk[((4 * g + r) * 16 + j) * 17] * dl;
+              if (lane < 16) {
+                Lgam[j * 16 + col] = gm;
+                Lmu[j * 16 + col] = mu;
+                Ldel[j * 16 + col] = dl;
+              }
+              m1o = m1o_n; cA = cA_n; cf = cf_n; ci = ci_n; dj = d_n;
+            }
+          }
+        }
+        } else {
+          // (with 16 residual tiles per wave the four-group form spills; the plain lane = trait form is faster there)
         // ---- sequential pass over the 16 SNPs, lane = trait (src/coreLoop.cpp:115-133) ----
         if (lane < 16) {
           const double *Gk = LGk + buf * (256 * 17) + col;
@@ -321,6 +372,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
             Ldel[j * 16 + col] = dl;
             m1o = m1o_n; cA = cA_n; cf = cf_n; ci = ci_n; dj = d_n;
           }
+        }
         }
       } else if (more) {
         compute_gk(b + 1, buf ^ 1);
