@@ -30,15 +30,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # FP64 peaks used for the roofline: AMD's public MI355X figure (vector = matrix FP64) and the
-# v_mfma_f64_16x16x4_f64 rate measured on this pool with tools/microbench/f64_peak.hip
+# v_mfma_f64_16x16x4_f64 rate measured on this pool with tools/microbench/f64_sustain.hip (77.8 TFLOP/s sustained over 27 ms)
 # (MI355X_MICROARCH.md has no FP64 row) -- see DESIGN.md section 6.
 PEAK_FP64_SPEC_TFLOPS = 78.6
-PEAK_FP64_MFMA_MEASURED_TFLOPS = 47.7
+PEAK_FP64_MFMA_MEASURED_TFLOPS = 77.8
 # HBM-side bytes of ONE core-sweep launch at the default workload on one GPU, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command with the gfx950
 # correction (FETCH_SIZE x 2 for coalesced streaming reads, calibrated on aq_k_prepass's gam read):
-# profiles/r01_pmc_hbm_traffic_v3.txt.  PMC counters cannot be read from inside the timed run.
-PMC_TRAFFIC_C3_BYTES = 4.90e10
+# profiles/r01_pmc_hbm_traffic_v4.txt.  PMC counters cannot be read from inside the timed run.
+PMC_TRAFFIC_C3_BYTES = 4.11e10
 
 
 def build_problem(n, p, q_total, k0, k1, device, seed=123):
@@ -260,7 +260,7 @@ def main():
                                                      3: "aq_core_sweep_mis_kernel"}[st1["core_kernel"]], "achieved": achieved,
                          "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,
                          "traffic": PMC_TRAFFIC_C3_BYTES if (n, p, q, world) == (1000, 50000, 10000, 1) else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic_v3.txt)",
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic_v4.txt)",
                          "algorithmic_bytes": 32.0 * p * q_loc + 8.0 * n * p + 16.0 * n * q_loc,
                          "peak_measured_mfma_f64": PEAK_FP64_MFMA_MEASURED_TFLOPS,
                          "frac_of_measured_mfma_peak": achieved / PEAK_FP64_MFMA_MEASURED_TFLOPS,
