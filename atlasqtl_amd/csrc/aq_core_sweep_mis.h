@@ -51,6 +51,8 @@ struct AqMisArgs {
   int *pflag;              // [ntile][C] number of blocks whose partial S this part has published
   int *errflag;            // set when a bounded wait expires
   double *rnpart;          // [C][q_pad] partial ||R_k||^2 of each part (C > 1)
+  int nseg;                // > 1 (C == 1 only): chained SNP segments as in aq_core_sweep_la.h, block s*ntile + k = segment s of tile k;
+  int *done;               //   done[tile] = segments of that tile already finished; sums land in slot s of 6 rows each
 };
 
 // NT: 16-sample residual tiles per wave; 8 waves, C parts: n_pad = 128 NT C.
@@ -59,7 +61,27 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
   constexpr int NW = 8;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, col = lane & 15;
-  const int tile = blockIdx.x / a.C, part = blockIdx.x - tile * a.C;
+  int tile_ = blockIdx.x / a.C, seg = 0, seg_b0 = 0, seg_b1 = a.nb;
+  const int part = blockIdx.x - tile_ * a.C;
+  if (a.nseg > 1) {
+    // chained SNP segments (more trait tiles than CUs): this workgroup continues tile k where segment s-1 left its residual
+    seg = blockIdx.x / a.ntile;
+    tile_ = blockIdx.x - seg * a.ntile;
+    seg_b0 = (int)((long long)a.nb * seg / a.nseg);
+    seg_b1 = (int)((long long)a.nb * (seg + 1) / a.nseg);
+    if (seg > 0) {
+      if (threadIdx.x == 0) {
+        int tries = 0;
+        while (__hip_atomic_load(&a.done[tile_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+          __builtin_amdgcn_s_sleep(32);
+          if (++tries > 4000000) { *a.errflag = 1; break; }   // bounded: never hang the GPU
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+    }
+  }
+  const int tile = tile_;
   const bool lead = (part == 0);          // the part that records the tile's results
   const int NTT = NT * NW * a.C;          // residual tiles of the whole sample axis
   const int wt0 = (part * NW + w) * NT;   // first residual tile of this wave
@@ -205,21 +227,22 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
     aq_d4 acc = (aq_d4){0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      double2 a0 = XAw[t * 128], a1 = XAw[t * 128 + 64];
+      const double2 *xa0 = XAw + (size_t)seg_b0 * NTT * 128;
+      double2 a0 = xa0[t * 128], a1 = xa0[t * 128 + 64];
       acc = aq_mfma(a0.x, Rr[t][0], acc);
       acc = aq_mfma(a0.y, Rr[t][1], acc);
       acc = aq_mfma(a1.x, Rr[t][2], acc);
       acc = aq_mfma(a1.y, Rr[t][3], acc);
       __builtin_amdgcn_sched_barrier(0);
     }
-    compute_gk(0, 0);
-    if (helper) stage_load(0);
+    compute_gk(seg_b0, seg_b0 & 1);
+    if (helper) stage_load(seg_b0);
     __syncthreads();
-    if (helper) stage_commit(0);
+    if (helper) stage_commit(seg_b0 & 1);
 
     bool dead = false;   // a bounded wait on a partner expired (reported through errflag)
-    for (int b = 0; b < a.nb; b++) {
-      const bool more = (b + 1 < a.nb);
+    for (int b = seg_b0; b < seg_b1; b++) {
+      const bool more = (b + 1 < seg_b1);
       const int buf = b & 1;
       if (helper && more) stage_load(b + 1);
 #pragma unroll
@@ -460,16 +483,41 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
     double r2 = 0.0;
 #pragma unroll 1
     for (int s = 0; s < NW * 4; s++) r2 += Lrn[s * 16 + tid];
+    double *sm = a.sums + (size_t)seg * 6 * Q;             // per-segment slot (combined by aq_k_combine_segment_sums6)
     if (a.C > 1) a.rnpart[(size_t)part * Q + kk] = r2;   // added over the parts by aq_k_sum_parts
-    else a.sums[4 * Q + kk] = r2;
+    else sm[4 * Q + kk] = r2;
 #pragma unroll 1
     for (int u = 0; u < 5 && lead; u++) {   // Lred rows: gam, m2, sx, gam*b, gam*log sig2_beta -> sums rows 0,1,2,3,5
       double acc2 = 0.0;
 #pragma unroll 1
       for (int jj = 0; jj < 16; jj++) acc2 += Lred[u * 256 + jj * 16 + tid];
-      a.sums[(size_t)(u < 4 ? u : 5) * Q + kk] = acc2;
+      sm[(size_t)(u < 4 ? u : 5) * Q + kk] = acc2;
     }
   }
+  if (a.nseg > 1) {
+    // publish this tile's residual for the next segment: stores drained, one agent-scope release, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&a.done[tile], seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// NA-form sums (6 rows per slot): rows 0-3 and 5 added over the chained segments, ||R||^2 (row 4) from the last one
+__global__ void aq_k_combine_segment_sums6(double *sums, int q_pad, int nslot) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= q_pad) return;
+  size_t Q = q_pad;
+  for (int v = 0; v < 6; v++) {
+    if (v == 4) continue;
+    double acc = sums[v * Q + k];
+    for (int s = 1; s < nslot; s++) acc += sums[(size_t)s * 6 * Q + v * Q + k];
+    sums[v * Q + k] = acc;
+  }
+  sums[4 * Q + k] = sums[(size_t)(nslot - 1) * 6 * Q + 4 * Q + k];
 }
 
 // X_b in row-major panels for the gathers: XR[(b*NR + i)*16 + jj] = x_{i, 16 b + jj} (0 beyond n or p)

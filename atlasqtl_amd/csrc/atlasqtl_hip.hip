@@ -252,16 +252,21 @@ static int aq_launch_mis(aq_vb *s, int mode, double c) {
   t.p = s->p; t.q = s->q; t.p_pad = s->p_pad; t.q_pad = s->q_pad; t.n_pad = s->n_pad; t.nb = s->nb; t.ntile = s->ntile;
   t.dmode = s->dmode; t.mode = mode; t.NR = s->NR; t.Mmax = s->Mmax;
   t.C = s->misC; t.Pbuf = s->Pbuf; t.pflag = s->pflag; t.errflag = s->errflag; t.rnpart = s->rnpart;
+  const int nseg = (mode == 0 && s->misC == 1 && s->chain > 1) ? s->chain : 1;
+  t.nseg = nseg; t.done = s->done;
+  if (nseg > 1) AQ_HIP(hipMemsetAsync(s->done, 0, (size_t)s->ntile * sizeof(int), 0));
   if (s->misC > 1) AQ_HIP(hipMemsetAsync(s->pflag, 0, (size_t)s->ntile * s->misC * sizeof(int), 0));
   size_t lds = (size_t)(8 * 256 + 11 * 256 + 5 * 256 + 8 * 4 * 16 + 2 * 256 * 17) * sizeof(double) + 16 * sizeof(int) +
                (size_t)16 * s->Mmax * sizeof(unsigned short);
 #define AQ_MIS(NT_)                                                                                             \
   if (s->NT == NT_) {                                                                                          \
     AQ_HIP(hipFuncSetAttribute((const void *)aq_core_sweep_mis_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((aq_core_sweep_mis_kernel<NT_>), dim3(s->ntile * s->misC), dim3(512), lds, 0, t);     \
+    hipLaunchKernelGGL((aq_core_sweep_mis_kernel<NT_>), dim3(s->ntile * s->misC * nseg), dim3(512), lds, 0, t); \
   } else
   AQ_MIS(1) AQ_MIS(2) AQ_MIS(4) AQ_MIS(8) AQ_MIS(16) { return aq_fail(AQ_ERR_UNSUPPORTED, "no masked MFMA kernel instantiation for this n"); }
 #undef AQ_MIS
+  if (nseg > 1)
+    hipLaunchKernelGGL(aq_k_combine_segment_sums6, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, nseg);
   if (s->misC > 1)
     hipLaunchKernelGGL(aq_k_sum_parts, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->rnpart, s->sums + (size_t)4 * s->q_pad, s->misC, s->q_pad);
   AQ_HIP(hipGetLastError());
@@ -509,6 +514,20 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       if (s->chain > 32) s->chain = 32;
     }
   }
+  if (s->use_mis && s->misC == 1) {   // same chained-segment choice as for the look-ahead kernel
+    if (s->ntile > s->ncu) {
+      double best = 1e30;
+      for (int S = 2; S <= 16; S++) {
+        long long wg = (long long)s->ntile * S;
+        double cost = (double)((wg + s->ncu - 1) / s->ncu) / S * (1.0 + 0.002 * S);
+        if (cost < best - 1e-12) { best = cost; s->chain = S; }
+      }
+      if (best >= (double)((s->ntile + s->ncu - 1) / s->ncu)) s->chain = 0;
+    }
+    if (const char *e = getenv("AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
+    if (s->chain > s->nb) s->chain = s->nb;
+    if (s->chain > 32) s->chain = 32;
+  }
   if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
   if (s->use_mis) { s->n_pad = 128 * s->NT * s->misC; s->NR = s->n_pad + 8; }
   if (s->use_tw) {
@@ -580,7 +599,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   double **qv[] = {&s->eta_h, &s->kappa_h, &s->n0, &s->nobs, &s->zeta, &s->tau, &s->sig2b, &s->log_tau, &s->eta_vb,
                    &s->kappa_vb, &s->coef, &s->inv2s, &s->cst};
   for (double **qp : qv) AQ_TRYF(aq_dalloc(qp, (size_t)s->q_pad));
-  AQ_TRYF(aq_dalloc(&s->sums, (size_t)5 * s->q_pad * (s->chain + 2)));   // one slot of 5 rows per chained segment (>= the 6 rows of the NA forms)
+  AQ_TRYF(aq_dalloc(&s->sums, (size_t)6 * s->q_pad * (s->chain + 2)));   // one slot of 5 (look-ahead) or 6 (NA forms) rows per chained segment
   AQ_TRYF(aq_dalloc(&s->done, (size_t)s->ntile));
   AQ_TRYF(aq_dalloc(&s->errflag, (size_t)1));
   AQ_TRYF(aq_dalloc(&s->rowA, (size_t)s->ntile * s->p_pad));

@@ -185,3 +185,14 @@ def test_missing_beyond_index_list_capacity_falls_back_to_generic():
     prob = make_problem(3000, 24, 5, p_act=4, prob_assoc=1.0, na_frac=0.4)
     assert np.isnan(prob["Y"]).sum(axis=0).max() > 1024
     _check_against_oracle(prob, 5, kernel=2)
+
+
+@pytest.mark.parametrize("chain", [2, 5])
+@pytest.mark.parametrize("shape,na", [((300, 130, 49), 0.04), ((200, 90, 33), 0.08)])
+def test_masked_kernel_chained_segments_match_oracle(shape, na, chain, monkeypatch):
+    """Chained SNP segments of the masked kernel (per-tile release/acquire hand-off of the residual, per-segment sums),
+    forced at small size with AQ_CHAIN."""
+    from tests.util import make_problem
+    monkeypatch.setenv("AQ_CHAIN", str(chain))
+    n, p, q = shape
+    _check_against_oracle(make_problem(n, p, q, p_act=8, prob_assoc=0.3, na_frac=na), q, kernel=3)

@@ -61,6 +61,8 @@ if __name__ == "__main__":
         timing(1000, 4000, 4096, sweeps=2, na_frac=0.05)
         timing(500, 4000, 4096, sweeps=2, na_frac=0.05)
         timing(2000, 2000, 4096, sweeps=2, na_frac=0.05)
+    if what == "mischain":   # more tiles than CUs with missing values: chained segments of the masked kernel
+        timing(1000, 3200, 10000, sweeps=2, na_frac=0.05)
     if what == "misbig":   # sample-split masked kernel at C5-like n
         timing(5000, 2000, 2512, sweeps=2, na_frac=0.05)
         timing(5000, 2000, 2512, sweeps=2)
