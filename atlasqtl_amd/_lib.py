@@ -33,6 +33,8 @@ class AqVbProblem(C.Structure):
         ("thinned_elbo_eval", C.c_int32), ("debug", C.c_int32),
         ("device", C.c_int32), ("world_size", C.c_int32),
         ("ext_reduce_main", C.c_void_p), ("ext_reduce_elbo", C.c_void_p), ("init_on_device", C.c_int32),
+        ("init_generate", C.c_int32), ("trait_offset", C.c_int32), ("init_seed", C.c_uint64),
+        ("init_gam_mean", C.c_double), ("init_gam_sd", C.c_double),
     ]
 
 

@@ -33,7 +33,7 @@ def add_collinear_back_(beta_vb, gam_vb, theta_vb, initial_colnames_X, rmvd_coll
 
 def atlasqtl(Y, X, p0, anneal=(1, 2, 10), tol=0.1, maxit=1000, user_seed=None, verbose=1, list_hyper=None,
              list_init=None, save_hyper=False, save_init=False, full_output=False, thinned_elbo_eval=True,
-             checkpoint_path=None, trace_path=None, add_collinear_back=False, device=0):
+             checkpoint_path=None, trace_path=None, add_collinear_back=False, device=0, device_init=False):
     """R/atlasqtl.R:179-322."""
     check_verbose_(verbose)
     check_annealing_(anneal)
@@ -49,7 +49,7 @@ def atlasqtl(Y, X, p0, anneal=(1, 2, 10), tol=0.1, maxit=1000, user_seed=None, v
     elif p0 is not None:
         warnings.warn("Provided argument p0 not used, as both list_hyper and list_init were provided.")
     list_hyper = prepare_list_hyper_(list_hyper, Yc, p, p0, bool_rmvd_x)
-    list_init = prepare_list_init_(list_init, Yc, p, p0, bool_rmvd_x, shr_fac_inv, user_seed)
+    list_init = prepare_list_init_(list_init, Yc, p, p0, bool_rmvd_x, shr_fac_inv, user_seed, device_init=device_init)
     if verbose != 0:
         print("**************************************************** \n"
               f"Number of samples: {n}\nNumber of (non-redundant) candidate predictors: {p}\n"

@@ -99,7 +99,7 @@ class VbRun:
     library copies them, drives the aq_vb_advance protocol and fetches results."""
 
     def __init__(self, Y, X, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval=True, debug=True,
-                 device=0, q_total=None, process_group=None):
+                 device=0, q_total=None, process_group=None, trait_offset=0):
         L = lib()
         Y = np.asfortranarray(Y, dtype=np.float64)
         X = np.asfortranarray(X, dtype=np.float64)
@@ -147,7 +147,15 @@ class VbRun:
         pr.eta = vec(list_hyper["eta"], q, "eta"); pr.kappa = vec(list_hyper["kappa"], q, "kappa")
         pr.n0 = vec(list_hyper["n0"], q, "n0")
         g0, m0_ = list_init["gam_vb"], list_init["mu_beta_vb"]
-        if hasattr(g0, "data_ptr"):
+        if g0 is None and m0_ is None:
+            # the p x q initial values are drawn on the device (hyper_init.auto_set_init_(..., device_init=True))
+            pr.init_generate = 1
+            pr.init_seed = int(list_init["device_seed"]) & 0xFFFFFFFFFFFFFFFF
+            pr.init_gam_mean = float(list_init["device_gam_mean"])
+            pr.init_gam_sd = float(list_init["device_gam_sd"])
+            pr.trait_offset = int(trait_offset)
+            pr.init_on_device = 0
+        elif hasattr(g0, "data_ptr"):
             # torch CUDA tensors holding the p x q matrices column-major, i.e. a contiguous (q, p) tensor
             for tname, tt in (("gam_vb", g0), ("mu_beta_vb", m0_)):
                 if not (tt.is_cuda and tt.is_contiguous() and tuple(tt.shape) == (q, p) and str(tt.dtype) == "torch.float64"):

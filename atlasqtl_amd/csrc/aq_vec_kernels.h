@@ -135,6 +135,47 @@ __global__ void aq_k_colmajor_from_tile(const double *__restrict__ src, const do
   }
 }
 
+// ----------------------------------------------- initial values on the device ----
+// auto_set_init_ (R/set_hyper_init.R:385-387): gam_vb = pnorm(rnorm(p q, mean = n0, sd = s02 + t02)), mu_beta_vb = rnorm(p q).
+// R's Mersenne-Twister stream cannot be reproduced anyway, so the draws come from a counter-based generator
+// that any shard can evaluate on its own: Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter = (SNP j, global
+// trait k, 0, 0); one call yields both normals of the entry (Box-Muller).  the CPU checker under tests/ restates the same stream.
+__host__ __device__ inline void aq_philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__host__ __device__ inline void aq_init_pair(uint64_t seed, uint32_t j, uint32_t k_global, double gam_mean, double gam_sd,
+                                             double *gam, double *mu) {
+  uint32_t c[4] = {j, k_global, 0u, 0u};
+  aq_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  // two uniforms in (0, 1) with 53 bits each
+  const double u1 = ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(c[2] >> 5) * 67108864.0 + (double)(c[3] >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+  const double r = sqrt(-2.0 * log(u1));
+  const double z1 = r * cos(6.283185307179586476925286766559 * u2), z2 = r * sin(6.283185307179586476925286766559 * u2);
+  *gam = 0.5 * erfc(-(gam_mean + gam_sd * z1) * 0.70710678118654752440084436210485);    // pnorm
+  *mu = z2;
+}
+// gam, mu in the trait-tiled layout [ntile][p_pad][16]; padding entries are 0
+__global__ void aq_k_init_generate(double *__restrict__ gam, double *__restrict__ mu, int p, int q, int p_pad, int ntile,
+                                   unsigned long long seed, int trait_offset, double gam_mean, double gam_sd) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)ntile * p_pad * 16;
+  if (e >= total) return;
+  int hk = (int)(e & 15);
+  size_t rest = e >> 4;
+  int j = (int)(rest % p_pad), tile = (int)(rest / p_pad);
+  int k = tile * 16 + hk;
+  double g = 0.0, m = 0.0;
+  if (j < p && k < q) aq_init_pair(seed, (uint32_t)j, (uint32_t)(trait_offset + k), gam_mean, gam_sd, &g, &m);
+  gam[e] = g;
+  mu[e] = m;
+}
+
 // ------------------------------------------------------------- pre-pass ----
 // Everything transcendental that the core sweep needs per (j,k) entry, from the current
 // theta_j + zeta_k (u):

@@ -396,7 +396,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   *out = nullptr;
   if (pr->n < 2 || pr->p < 1 || pr->q < 1) return aq_fail(AQ_ERR_ARG, "aq_vb_create: n >= 2, p >= 1, q >= 1 required");
   if (pr->q_total < pr->q) return aq_fail(AQ_ERR_ARG, "aq_vb_create: q_total < q");
-  if (!pr->X || !pr->Y || !pr->eta || !pr->kappa || !pr->n0 || !pr->gam_vb || !pr->mu_beta_vb || !pr->sig2_beta_vb ||
+  if (!pr->X || !pr->Y || !pr->eta || !pr->kappa || !pr->n0 || (!pr->init_generate && (!pr->gam_vb || !pr->mu_beta_vb)) || !pr->sig2_beta_vb ||
       !pr->sig2_theta_vb || !pr->tau_vb || !pr->theta_vb || !pr->zeta_vb)
     return aq_fail(AQ_ERR_ARG, "aq_vb_create: NULL data pointer");
   if (!(pr->tol > 0)) return aq_fail(AQ_ERR_ARG, "tol must be positive");
@@ -639,7 +639,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     }
   }
   {
-    size_t big = pr->init_on_device ? nq : std::max((size_t)pr->p * pr->q, nq);
+    size_t big = (pr->init_on_device || pr->init_generate) ? nq : std::max((size_t)pr->p * pr->q, nq);
     double *stage = nullptr;
     AQ_HIPF(hipMalloc((void **)&stage, big * sizeof(double)));
     AQ_HIPF(hipMemcpy(stage, pr->Y, nq * sizeof(double), hipMemcpyHostToDevice));
@@ -656,6 +656,13 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     }
     size_t pq = (size_t)pr->p * pr->q;
     const double *gsrc = pr->gam_vb, *msrc = pr->mu_beta_vb;
+    if (pr->init_generate) {
+      if (!(pr->init_gam_sd > 0.0)) { AQ_HIPF(hipFree(stage)); aq_fail(AQ_ERR_ARG, "init_gam_sd must be positive"); return fail(AQ_ERR_ARG); }
+      size_t tot = (size_t)s->ntile * s->p_pad * 16;
+      hipLaunchKernelGGL(aq_k_init_generate, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, s->gam, s->mu, s->p, s->q, s->p_pad,
+                         s->ntile, (unsigned long long)pr->init_seed, (int)pr->trait_offset, pr->init_gam_mean, pr->init_gam_sd);
+      AQ_HIPF(hipDeviceSynchronize());
+    } else {
     if (!pr->init_on_device) {
       AQ_HIPF(hipMemcpy(stage, pr->gam_vb, pq * sizeof(double), hipMemcpyHostToDevice));
       gsrc = stage;
@@ -670,6 +677,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->p_pad + 63) / 64, s->ntile), dim3(256), 0, 0, msrc, s->mu,
                        s->p, s->q, s->p_pad, 0);
     AQ_HIPF(hipDeviceSynchronize());
+    }
     AQ_HIPF(hipFree(stage));
   }
   AQ_TRYF(aq_upload_padded(s->theta, pr->theta_vb, s->p, s->p_pad));

@@ -120,16 +120,22 @@ def set_init(q, p, gam_vb, mu_beta_vb, sig02_inv_vb, sig2_beta_vb, sig2_theta_vb
     return li
 
 
-def auto_set_init_(Y, p, p0, shr_fac_inv, user_seed):
-    """R/set_hyper_init.R:356-418 (same distributions, NumPy generator)."""
+def auto_set_init_(Y, p, p0, shr_fac_inv, user_seed, device_init=False):
+    """R/set_hyper_init.R:356-418 (same distributions, NumPy generator).  device_init: the two p x q matrices are not
+    drawn here but on the GPU when the run is created (Philox stream keyed by the seed; gam_vb / mu_beta_vb are None and
+    the list carries device_seed, device_gam_mean, device_gam_sd) -- no 2 x 8pq bytes on the host."""
     q = Y.shape[1]
     rng = np.random.default_rng(user_seed)
     t02 = _solve_t02(p, p0)
     n0 = get_mu(float(p0[0]), t02, p)
     s02 = 1e-4
     check_positive_(t02, "t02")
-    gam_vb = stats.norm.cdf(rng.normal(loc=n0, scale=s02 + t02, size=(p, q)))        # :385  [sic: sd]
-    mu_beta_vb = rng.normal(size=(p, q))                                             # :387
+    if device_init:
+        gam_vb = mu_beta_vb = None
+        device_seed = int(rng.integers(0, 2 ** 63 - 1))
+    else:
+        gam_vb = stats.norm.cdf(rng.normal(loc=n0, scale=s02 + t02, size=(p, q)))    # :385  [sic: sd]
+        mu_beta_vb = rng.normal(size=(p, q))                                         # :387
     sig2_inv_vb = 1e-2
     with np.errstate(divide="ignore"):
         tau = 1.0 / _median_col_var(Y)                                               # :391
@@ -145,6 +151,8 @@ def auto_set_init_(Y, p, p0, shr_fac_inv, user_seed):
                   sig2_beta_vb=sig2_beta_vb, sig2_theta_vb=sig2_theta_vb, tau_vb=tau_vb, theta_vb=theta_vb,
                   zeta_vb=zeta_vb)
     li.cls = "out_init"
+    if device_init:
+        li["device_seed"], li["device_gam_mean"], li["device_gam_sd"] = device_seed, float(n0), float(s02 + t02)
     return li
 
 
@@ -169,11 +177,11 @@ def prepare_list_hyper_(list_hyper, Y, p, p0, bool_rmvd_x):
     return out
 
 
-def prepare_list_init_(list_init, Y, p, p0, bool_rmvd_x, shr_fac_inv, user_seed):
+def prepare_list_init_(list_init, Y, p, p0, bool_rmvd_x, shr_fac_inv, user_seed, device_init=False):
     """R/prepare_atlasqtl.R:189-248."""
     q = Y.shape[1]
     if list_init is None:
-        return auto_set_init_(Y, p, p0, shr_fac_inv, user_seed)
+        return auto_set_init_(Y, p, p0, shr_fac_inv, user_seed, device_init=device_init)
     if not isinstance(list_init, ListInit):
         raise AtlasqtlError("The provided list_init must be an object of class ``init'' or `` out_init''. \n "
                             "*** you must either use the function set_init to set your own initialization or "

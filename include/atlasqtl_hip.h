@@ -107,6 +107,14 @@ typedef struct aq_vb_problem {
   double *ext_reduce_elbo;     /* optional DEVICE buffer of 8 doubles, same purpose                   */
   int32_t init_on_device;      /* 1: gam_vb and mu_beta_vb are DEVICE pointers (p x q column-major) on
                                   `device`; avoids staging 2 x 8pq bytes through the host              */
+  /* SURVEY 8f N1 -- the p x q initial values of auto_set_init_ (R/set_hyper_init.R:385-387) drawn ON the
+   * device: gam_vb = pnorm(N(init_gam_mean, sd = init_gam_sd)), mu_beta_vb = N(0, 1), from Philox4x32-10 keyed by
+   * init_seed with counter (SNP index, trait_offset + local trait index): the draws of a trait do not depend
+   * on how the traits are sharded.  gam_vb and mu_beta_vb may then be NULL.                                  */
+  int32_t init_generate;
+  int32_t trait_offset;        /* global index of this process's first trait (0 on one GPU)              */
+  uint64_t init_seed;
+  double init_gam_mean, init_gam_sd;
 } aq_vb_problem;
 
 /* Length (in doubles) of the main all-reduce payload for a problem with p predictors:

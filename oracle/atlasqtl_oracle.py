@@ -633,3 +633,36 @@ def hotspot_sizes(gam_vb, thres, fdr_adjust=False):
     else:
         m = np.asarray(gam_vb) > thres
     return m.sum(axis=1).astype(np.int64), int(m.sum())
+
+
+# ----------------------------------------------------------------------------
+# initial values drawn with the build's counter-based generator
+# ----------------------------------------------------------------------------
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), vectorised:
+    ctr = 4 uint32 arrays, key = 2 ints.  Known-answer vectors of the Random123 distribution are in tests/test_oracle.py."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    c = [np.asarray(x, dtype=np.uint64) for x in ctr]
+    k0, k1 = int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF
+    lo = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0), p1 & lo, (p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1), p0 & lo]
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c
+
+
+def philox_init(seed, p, q, gam_mean, gam_sd, trait_offset=0):
+    """gam_vb, mu_beta_vb of auto_set_init_ (R/set_hyper_init.R:385-387: pnorm(rnorm(p q, n0, sd = s02 + t02)), rnorm(p q))
+    from the counter-based stream the device uses (aq_init_pair, atlasqtl_amd/csrc/aq_vec_kernels.h): counter
+    (SNP j, global trait k, 0, 0), key = seed; two 53-bit uniforms -> Box-Muller."""
+    j = np.broadcast_to(np.arange(p, dtype=np.uint64)[:, None], (p, q))
+    k = np.broadcast_to((np.arange(q, dtype=np.uint64) + np.uint64(trait_offset))[None, :], (p, q))
+    z = np.zeros((p, q), dtype=np.uint64)
+    c = philox4x32_10([j, k, z, z], [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF])
+    u1 = ((c[0] >> np.uint64(5)).astype(np.float64) * 67108864.0 + (c[1] >> np.uint64(6)).astype(np.float64) + 0.5) / 9007199254740992.0
+    u2 = ((c[2] >> np.uint64(5)).astype(np.float64) * 67108864.0 + (c[3] >> np.uint64(6)).astype(np.float64) + 0.5) / 9007199254740992.0
+    r = np.sqrt(-2.0 * np.log(u1))
+    z1, z2 = r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)
+    gam = sp.ndtr(gam_mean + gam_sd * z1)
+    return np.asfortranarray(gam), np.asfortranarray(z2)

@@ -160,3 +160,69 @@ def test_checkpoint_path_and_resume(tmp_path):
     assert again["it"] == ref["it"]
     np.testing.assert_array_equal(again["gam_vb"], ref["gam_vb"])
     np.testing.assert_array_equal(again["elbo_trace"][1], ref["elbo_trace"][1])
+
+
+def _device_init_list(prob, seed=20240607):
+    li = dict(prob["list_init"])
+    li["gam_vb"] = li["mu_beta_vb"] = None
+    li["device_seed"], li["device_gam_mean"], li["device_gam_sd"] = seed, float(np.asarray(prob["list_hyper"]["n0"])[0]), 0.37
+    return li
+
+
+def test_device_generated_init_equals_the_oracle_stream_and_runs_like_it():
+    """gam_vb / mu_beta_vb of auto_set_init_ (R/set_hyper_init.R:385-387) drawn on the device from the
+    Philox stream; the oracle restates the stream, so 'same (X, Y), same init' holds on both sides."""
+    import atlasqtl_amd as A
+    from atlasqtl_amd.core import VbRun
+    from oracle import atlasqtl_oracle as O
+    from tests.util import make_problem
+    prob = make_problem(200, 130, 49, p_act=10, prob_assoc=0.3)
+    li = _device_init_list(prob)
+    run = VbRun(prob["Y"], prob["X"], prob["list_hyper"], li, (1, 2, 10), 0.1, 400, True, True)
+    run.run_sweeps(0)
+    res0 = run.result(full_output=True)
+    run.close()
+    g_ref, m_ref = O.philox_init(li["device_seed"], 130, 49, li["device_gam_mean"], li["device_gam_sd"])
+    np.testing.assert_allclose(res0["gam_vb"], g_ref, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(res0["mu_beta_vb"], m_ref, rtol=1e-12, atol=1e-15)
+    # the whole run from the device-drawn init == the oracle's run from the restated init
+    li_ref = dict(prob["list_init"], gam_vb=g_ref, mu_beta_vb=m_ref)
+    tr = []
+    ref = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], 49, (1, 2, 10), 1, 0.1, 400, prob["list_hyper"], li_ref, trace=tr,
+                                        full_output=True)
+    got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 49, (1, 2, 10), 1, 0.1, 400, 0, prob["list_hyper"], li,
+                                        full_output=True, debug=True)
+    assert got["it"] == ref["it"]
+    np.testing.assert_allclose(got["mu_beta_vb"], ref["mu_beta_vb"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], atol=1e-9)
+
+
+def test_device_generated_init_does_not_depend_on_sharding():
+    from atlasqtl_amd.core import VbRun
+    from tests.util import make_problem
+    prob = make_problem(120, 60, 40, p_act=6)
+    li = _device_init_list(prob)
+    full = VbRun(prob["Y"], prob["X"], prob["list_hyper"], li, None, 0.1, 10, True, True)
+    full.run_sweeps(0)
+    g_full = full.result()["gam_vb"]
+    full.close()
+    k0 = 16
+    lh, li2 = dict(prob["list_hyper"]), dict(li)
+    for k in ("eta", "kappa", "n0"):
+        lh[k] = np.asarray(lh[k])[k0:]
+    for k in ("sig2_beta_vb", "tau_vb", "zeta_vb"):
+        li2[k] = np.asarray(li2[k])[k0:]
+    shard = VbRun(prob["Y"][:, k0:], prob["X"], lh, li2, None, 0.1, 10, True, True, q_total=40, trait_offset=k0)
+    shard.run_sweeps(0)
+    g_sh = shard.result()["gam_vb"]
+    shard.close()
+    np.testing.assert_array_equal(g_sh, g_full[:, k0:])
+
+
+def test_atlasqtl_with_device_init_converges():
+    import atlasqtl_amd as A
+    X, Y, d = _data(100, 75, 20, seed=123)
+    vb = A.atlasqtl(Y=Y, X=X, p0=(5, 25), user_seed=1, verbose=0, device_init=True)
+    assert vb.converged is True
+    top = set(np.argsort(-vb.gam_vb.sum(1))[:6])
+    assert len(top & set(d["act_x"])) >= 4

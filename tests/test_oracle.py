@@ -149,3 +149,24 @@ def test_assign_bfdr_restatement_properties():
     assert np.isclose(fv[order[-1]], np.mean(1 - v))
     rs, nb = O.hotspot_sizes(m, 0.5)
     assert nb == int((m > 0.5).sum()) and rs.shape == (40,)
+
+
+def test_philox4x32_10_known_answers():
+    """Known-answer vectors of the Random123 distribution (kat_vectors, philox4x32 with 10 rounds)."""
+    from oracle import atlasqtl_oracle as O
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10([np.array([c], dtype=np.uint64) for c in ctr], key)
+        assert tuple(int(g[0]) for g in got) == want
+    from scipy import special as sp
+    gam, mu = O.philox_init(12345, 400, 30, -2.0, 0.3)
+    assert gam.shape == (400, 30) and 0 < gam.min() and gam.max() < 1
+    assert abs(mu.mean()) < 0.05 and abs(mu.std() - 1) < 0.05                 # N(0, 1)
+    z = (sp.ndtri(gam) + 2.0) / 0.3
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05                   # pnorm(N(-2, sd 0.3))
+    g2, m2 = O.philox_init(12345, 400, 10, -2.0, 0.3, trait_offset=20)        # a shard reproduces its own columns
+    np.testing.assert_array_equal(g2, gam[:, 20:])
+    np.testing.assert_array_equal(m2, mu[:, 20:])
