@@ -149,6 +149,13 @@ def cpu_baseline(n, p, q_total, seed=7, budget_s=10.0):
            "sample": f"oracle n-space core loop (step S9 only), {q_sub} of {q_total} traits at full n={n}, p={p}, "
                      f"{per_trait * q_sub:.1f} s measured, scaled by q/q_sub"}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:   # a container's CPU share (cgroup v2 quota) is what the threads can really use
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, 64)
     if cores > 1:
         qs = max(cores, min(4096, int(cores * 6.0 / max(per_trait, 1e-9))))     # ~6 s of wall-clock
         qs -= qs % cores
