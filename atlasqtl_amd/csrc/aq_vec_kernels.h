@@ -325,7 +325,7 @@ __global__ void aq_k_reduce_rows(const double *__restrict__ rowA, const double *
   for (int t = 0; t < ntile; t++) {
     double gb = rowGB[(size_t)t * gb_rows * p_pad + j];
     for (int r = 1; r < gb_rows; r++) gb += rowGB[((size_t)t * gb_rows + r) * p_pad + j];
-    s += rowA[(size_t)t * p_pad + j] + gb;
+    s += (rowA ? rowA[(size_t)t * p_pad + j] : 0.0) + gb;   // rowA == NULL: the sweep kernel already folded a into rowGB
   }
   red[j] = s;
 }

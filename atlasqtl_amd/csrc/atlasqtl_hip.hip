@@ -602,9 +602,9 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   AQ_TRYF(aq_dalloc(&s->sums, (size_t)6 * s->q_pad * (s->chain + 2)));   // one slot of 5 (look-ahead) or 6 (NA forms) rows per chained segment
   AQ_TRYF(aq_dalloc(&s->done, (size_t)s->ntile));
   AQ_TRYF(aq_dalloc(&s->errflag, (size_t)1));
-  AQ_TRYF(aq_dalloc(&s->rowA, (size_t)s->ntile * s->p_pad));
+  s->fused = s->use_la;   // the look-ahead kernel computes A, b and the sums of a itself: no pre-pass arrays
+  if (!s->fused) AQ_TRYF(aq_dalloc(&s->rowA, (size_t)s->ntile * s->p_pad));
   AQ_TRYF(aq_dalloc(&s->rowGB, (size_t)s->ntile * s->WPT * s->p_pad));
-  s->fused = s->use_la;
   if (!s->fused) {   // the other kernels read A and b from the pre-pass arrays
     AQ_TRYF(aq_dalloc(&s->Aarr, (size_t)s->ntile * s->p_pad * 16));
     AQ_TRYF(aq_dalloc(&s->Barr, (size_t)s->ntile * s->p_pad * 16));
@@ -759,7 +759,8 @@ static int aq_sweep_part_a(aq_vb *s) {
   s->pre_done = false;
   hipLaunchKernelGGL(aq_k_qpre, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, qv, s->sc, s->c);
   AQ_TRY(aq_launch_core(s, 0, s->c));
-  hipLaunchKernelGGL(aq_k_reduce_rows, dim3((s->p_pad + 255) / 256), dim3(256), 0, 0, s->rowA, s->rowGB, s->red, s->ntile, s->p_pad, s->WPT);
+  hipLaunchKernelGGL(aq_k_reduce_rows, dim3((s->p_pad + 255) / 256), dim3(256), 0, 0, s->fused ? (const double *)nullptr : s->rowA, s->rowGB,
+                     s->red, s->ntile, s->p_pad, s->WPT);
   hipLaunchKernelGGL(aq_k_reduce_q_scalars, dim3(1), dim3(1024), 0, 0, qv, s->red + s->p_pad);
   AQ_HIP(hipGetLastError());
   return AQ_OK;
