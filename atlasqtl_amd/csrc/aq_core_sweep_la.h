@@ -78,6 +78,26 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   __shared__ double Lgam[2][256], Lmu[2][256], Ldel[2][256];
   __shared__ double Lred[4][256];      // running column sums per helper thread
   __shared__ double Lrn[NWM * 4][16];
+  // Point-to-point progress counters instead of a workgroup barrier per phase (sweep mode): Fl[0..5] = number of SNP
+  // blocks whose partial S' matrix wave m has written, Fl[6] = blocks the recurrence wave has finished, Fl[7] = blocks
+  // the helper wave has staged.  Each wave waits only for what it really reads, so the matrix waves -- the critical
+  // path -- never stop at a barrier (it cost them 0.3 us of LDS congestion after, 0.3 us of MFMA drain before and the
+  // skew of eight waves, per 5.9 us phase).  LDS operations of a wave execute in order and the LDS is one pipeline per
+  // CU, so "data stores; s_waitcnt lgkmcnt(0); counter store" on one side and "counter load ... ; data loads" on the
+  // other are ordered; the asm memory clobbers keep the compiler from moving accesses across them.
+  __shared__ int Fl[8];
+  // (explicit LDS address space: through a generic pointer the volatile accesses become flat loads with a vmcnt(0) drain)
+  typedef __attribute__((address_space(3))) volatile int aq_lds_vint;
+  aq_lds_vint *Flv = (aq_lds_vint *)(__attribute__((address_space(3))) int *)Fl;
+  auto signal = [&](int idx, int val) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) Flv[idx] = val;
+  };
+  auto wait_ge = [&](int idx, int val) {
+    while (Flv[idx] < val) __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+  };
+  if (tid < 8) Fl[tid] = 0;
 
   const size_t tbase = (size_t)tile * a.p_pad * 16;
   double *Rg = a.R + (size_t)tile * a.n_pad * 16;
@@ -95,10 +115,10 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     }
   }
 
+  __syncthreads();   // counters and the helper's LDS initialisation are visible to every role
   if (is_rec) {
     // =========================== recurrence wave ===========================================
-    // highest issue priority on its SIMD: the helper wave (same SIMD) only gets the slots the dependent chain leaves free
-    __builtin_amdgcn_s_setprio(3);
+
     if (a.mode == 1) {
       for (int b = seg_b0; b < seg_b1; b++) {   // init mode: nothing to do, keep the barrier count
         __syncthreads();
@@ -110,9 +130,14 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const double rc_cinv2s = a.c * a.inv2s[kk];
       const double rc_cst = a.cst[kk];
       const double rc_K = rc_coef * rc_coef * rc_cinv2s;   // keeps mu off the dependency chain of the recursion
-      aq_lds_barrier();   // prologue
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
+        {   // block b needs its six partial S' and its staged scalars
+          const int need = b - seg_b0 + 1;
+#pragma unroll
+          for (int m = 0; m < NWM; m++) wait_ge(m, need);
+          wait_ge(7, need);
+        }
 #if AQ_DIAG & 8
         const long long t_in = clock64();
 #endif
@@ -174,7 +199,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #if AQ_DIAG & 8
         const long long t_work = clock64();
 #endif
-        aq_lds_barrier();
+        signal(6, b - seg_b0 + 1);   // delta, gam, mu of block b are in LDS
 #if AQ_DIAG & 8
         if (blockIdx.x == 0 && lane == 0 && a.dbg && (b - seg_b0) < 256) {
           long long *d = a.dbg + ((size_t)(b - seg_b0) * 16 + w) * 3;
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       stage_probit(seg_b0);
       if (seg_b0 + 1 < seg_b1) theta_load(seg_b0 + 1);
       stage_commit(seg_b0 & 1);
-      aq_lds_barrier();   // prologue
+      signal(7, 1);
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
         const bool more = (b + 1 < seg_b1);
@@ -302,14 +327,15 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         const long long t_in = clock64();
 #endif
         if (more) stage_load(b + 1);
-        if (b > seg_b0) finalize(b - 1, par ^ 1);
         if (more) stage_probit(b + 1);
         if (b + 2 < seg_b1) theta_load(b + 2);
-        if (more) stage_commit(par ^ 1);
+        // block b-1 must be through the recurrence: its gam / mu are read here, and the parity buffers about to be
+        // overwritten with block b+1 are the ones it read
+        if (b > seg_b0) { wait_ge(6, b - seg_b0); finalize(b - 1, par ^ 1); }
+        if (more) { stage_commit(par ^ 1); signal(7, b - seg_b0 + 2); }
 #if AQ_DIAG & 8
         const long long t_work = clock64();
 #endif
-        aq_lds_barrier();
 #if AQ_DIAG & 8
         if (blockIdx.x == 0 && lane == 0 && a.dbg && (b - seg_b0) < 256) {
           long long *d = a.dbg + ((size_t)(b - seg_b0) * 16 + w) * 3;
@@ -317,6 +343,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         }
 #endif
       }
+      wait_ge(6, seg_b1 - seg_b0);
       finalize(seg_b1 - 1, (seg_b1 - 1) & 1);
     }
     __syncthreads();   // matches the matrix waves' barrier before the final sums
@@ -401,23 +428,26 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       // ---------------- full sweep -----------------------------------------------------
       // prologue: S'_0 from the untouched residual, staging of block 0
       matrix_phase(false, 0, 0, true, seg_b0, seg_b0 & 1, false);
+      signal(mw, 1);
       prefetch_first(0, seg_b0 + 1 < seg_b1, seg_b0 + 1);   // first phase: no update yet, S' of block seg_b0 + 1
-      aq_lds_barrier();
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
         const bool more = (b + 1 < seg_b1);
-        // update with block b-1, S' of block b+1
+        // update with block b-1 (its delta must be out: recurrence counter), S' of block b+1
 #if AQ_DIAG & 8
         const long long t_in = clock64();
 #endif
+        if (b > seg_b0) wait_ge(6, b - seg_b0);
 #if !(AQ_DIAG & 2)
         if (b > seg_b0 || more) matrix_phase(b > seg_b0, b - 1, par ^ 1, more, b + 1, par ^ 1, true);
+        if (more) signal(mw, b - seg_b0 + 2);
         prefetch_first(b, b + 2 < seg_b1, b + 2);   // next phase (or the epilogue): update with block b, S' of block b + 2
+#else
+        if (more) signal(mw, b - seg_b0 + 2);
 #endif
 #if AQ_DIAG & 8
         const long long t_work = clock64();
 #endif
-        aq_lds_barrier();
 #if AQ_DIAG & 8
         if (blockIdx.x == 0 && lane == 0 && a.dbg && (b - seg_b0) < 256) {
           long long *d = a.dbg + ((size_t)(b - seg_b0) * 16 + w) * 3;
@@ -427,6 +457,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       }
       // epilogue: the last block's update and stores
       const int pl = (seg_b1 - 1) & 1;
+      wait_ge(6, seg_b1 - seg_b0);
 #if !(AQ_DIAG & 2)
       matrix_phase(true, seg_b1 - 1, pl, false, 0, 0, true);
 #endif
