@@ -374,8 +374,15 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       constexpr int NTC = decltype(ntc)::value;
       double nd[4];
       if (do_u) {
+        // (4 s + g) 16 + col = 64 s + lane.  The lane id is recomputed here and hidden from the optimiser: kept in a
+        // register across the phase it was spilled, and the reload's s_waitcnt vmcnt(0) drained the operand prefetch of
+        // every phase -- 0.5 us of exposed L2 latency.
+        unsigned zero = 0;
+        asm volatile("" : "+v"(zero));   // opaque input: the two v_mbcnt are re-issued every phase instead of being hoisted and spilled
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+        const double *dl = &Ldel[pu][ln];
 #pragma unroll
-        for (int s = 0; s < 4; s++) nd[s] = -Ldel[pu][(4 * s + g) * 16 + col];
+        for (int s = 0; s < 4; s++) nd[s] = -dl[64 * s];
       }
       aq_d4 acc = {0, 0, 0, 0};
       const double2 *xu = XUw + (size_t)(do_u ? bu : 0) * NTT * 128;

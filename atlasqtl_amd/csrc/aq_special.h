@@ -38,12 +38,51 @@ AQ_HD double aq_log_ndtr(double x) {
   return -0.5 * x * x - log(-x) - AQ_LOG_SQRT_2PI + log(ser);
 }
 
+// The same function with a short dependency chain, for the sequential SNP recursion where every dependent fp64
+// operation costs ~10 ns per SNP and trait tile: exp(-|x|) by a two-step Cody-Waite reduction and a degree-12
+// Taylor polynomial in Estrin form (depth 4 instead of 11), the reciprocal of 1 + e in [1, 2] by v_rcp_f64 and two
+// Newton steps (no div_scale / div_fixup needed in that range).  21 dependent operations per SNP instead of 36;
+// relative error <= 3e-16 (tests/test_special.py).
+AQ_HD double aq_exp_neg_fast(double ax) {   // exp(-ax) for ax >= 0
+  ax = fmin(ax, 800.0);                     // exp(-800) = 0 in fp64; keeps the reduction finite for any input
+  const double k = rint(ax * -1.44269504088896340736);
+  double r = fma(k, -6.93147180369123816490e-01, -ax);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  const double r2 = r * r;
+  const double p01 = 1.0 + r;
+  const double p23 = fma(r, 1.0 / 6.0, 0.5);
+  const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  const double p67 = fma(r, 1.0 / 5040.0, 1.0 / 720.0);
+  const double p89 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0);
+  const double pAB = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0);
+  const double r4 = r2 * r2;
+  const double q0 = fma(p23, r2, p01);
+  const double q1 = fma(p67, r2, p45);
+  const double q2 = fma(pAB, r2, p89);
+  const double r8 = r4 * r4;
+  const double s0 = fma(q1, r4, q0);
+  const double s1 = fma(1.0 / 479001600.0, r4, q2);
+  return ldexp(fma(s1, r8, s0), (int)k);
+}
+// 1/d for a positive normal d: v_rcp_f64 plus two Newton steps on the device (no div_scale / div_fixup sequence), the
+// plain quotient on the host.
+AQ_HD double aq_recip_pos(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+  return y;
+#else
+  return 1.0 / d;
+#endif
+}
+
 // erfcx(z) = exp(z^2) erfc(z) for z >= 0: Chebyshev series in t = 4/(4+z) (coefficients from
 // tools/gen_erfcx_cheb.py, truncation 4e-18 relative), Clenshaw recurrence.  No exponential, no branch, no
 // underflow for any z -- which is why the pre-pass is built on it rather than on erfc.
 AQ_HD double aq_erfcx_pos(double z) {
   const double c[AQ_ERFCX_NCOEF] = {AQ_ERFCX_COEFS};
-  const double t = 4.0 / (4.0 + z);
+  const double t = 4.0 * aq_recip_pos(4.0 + z);
   const double x2 = 4.0 * t - 2.0;   // 2 (2t - 1)
   double b1 = 0.0, b2 = 0.0;
 #if defined(__HIPCC__)
@@ -89,10 +128,10 @@ AQ_HD void aq_probit_A_imr(double x, double *A, double *imr1, double *imr0, doub
   const double w = aq_erfcx_pos(fabs(x) * AQ_INV_SQRT2);
   const double hx2 = 0.5 * x * x;
   const double hx2_lo = 0.5 * fma(x, x, -(x * x));
-  const double E = exp(-hx2) * (1.0 - hx2_lo);
+  const double E = aq_exp_neg_fast(hx2) * (1.0 - hx2_lo);
   const double e = 0.5 * w * E;
   const double om = 1.0 - e;
-  const double r = 1.0 / (w * om);
+  const double r = aq_recip_pos(w * om);
   const double inv_w = r * om, inv_om = r * w;
   const double rf = AQ_SQRT_2_OVER_PI * inv_w;
   const double rn = (AQ_INV_SQRT_2PI * E) * inv_om;
@@ -121,32 +160,7 @@ AQ_HD double aq_sigmoid_neg(double x) {
   return num / (1.0 + e);
 }
 
-// The same function with a short dependency chain, for the sequential SNP recursion where every dependent fp64
-// operation costs ~10 ns per SNP and trait tile: exp(-|x|) by a two-step Cody-Waite reduction and a degree-12
-// Taylor polynomial in Estrin form (depth 4 instead of 11), the reciprocal of 1 + e in [1, 2] by v_rcp_f64 and two
-// Newton steps (no div_scale / div_fixup needed in that range).  21 dependent operations per SNP instead of 36;
-// relative error <= 3e-16 (tests/test_special.py).
-AQ_HD double aq_exp_neg_fast(double ax) {   // exp(-ax) for ax >= 0
-  ax = fmin(ax, 800.0);                     // exp(-800) = 0 in fp64; keeps the reduction finite for any input
-  const double k = rint(ax * -1.44269504088896340736);
-  double r = fma(k, -6.93147180369123816490e-01, -ax);
-  r = fma(k, -1.90821492927058770002e-10, r);
-  const double r2 = r * r;
-  const double p01 = 1.0 + r;
-  const double p23 = fma(r, 1.0 / 6.0, 0.5);
-  const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-  const double p67 = fma(r, 1.0 / 5040.0, 1.0 / 720.0);
-  const double p89 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0);
-  const double pAB = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0);
-  const double r4 = r2 * r2;
-  const double q0 = fma(p23, r2, p01);
-  const double q1 = fma(p67, r2, p45);
-  const double q2 = fma(pAB, r2, p89);
-  const double r8 = r4 * r4;
-  const double s0 = fma(q1, r4, q0);
-  const double s1 = fma(1.0 / 479001600.0, r4, q2);
-  return ldexp(fma(s1, r8, s0), (int)k);
-}
+// exp(-log(1+exp(x))) with the short chain (see aq_exp_neg_fast above).
 AQ_HD double aq_sigmoid_neg_fast(double x) {
   const double e = aq_exp_neg_fast(fabs(x));
   const double d = 1.0 + e;
