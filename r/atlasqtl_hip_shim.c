@@ -2,7 +2,8 @@
  * atlasqtl_hip_shim.c -- the thin .Call shim an atlasqtl maintainer adds to bind the R package
  * to libatlasqtl_hip.so.  It is compiled by R CMD SHLIB / the package's
  * src/Makevars where R exists; it cannot be built in the development image (no R headers), so it
- * is kept to the R C API subset listed below and is compile-checked only by inspection.
+ * is kept to the R C API subset listed below (syntax-checked with gcc -fsyntax-only against throw-away
+ * declarations of exactly that subset, outside the repository).
  *
  * It provides
  *   _atlasqtl_coreDualLoop / _atlasqtl_coreDualMisLoop   same names, arities (15 / 16) and
