@@ -57,7 +57,6 @@ if __name__ == "__main__":
         timing(1000, 5000, 4096)
         timing(2000, 3000, 1024)
     if what == "mis":   # masked MFMA kernel vs generic kernel, same data
-        parity(200, 90, 33) if False else None
         timing(1000, 4000, 4096, sweeps=2, na_frac=0.05)
         timing(500, 4000, 4096, sweeps=2, na_frac=0.05)
         timing(2000, 2000, 4096, sweeps=2, na_frac=0.05)
