@@ -390,29 +390,42 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       double2 cu0, cu1, ca0, ca1;
       if (pre) { cu0 = fu0; cu1 = fu1; ca0 = fa0; ca1 = fa1; }   // tile 0 was requested before the previous barrier
       else { cu0 = xu[0]; cu1 = xu[64]; ca0 = xa[0]; ca1 = xa[64]; }
+      // S' runs one tile behind the update: step t issues U(t) (4 MFMAs chained on Rr[t]) and then S'(t-1) (4 chained on
+      // acc), whose B operand Rr[t-1] was finished a whole step earlier -- a wave that runs alone on its SIMD (the two waves
+      // of a SIMD are ~1.3 us apart) no longer waits one MFMA latency per tile.  Same registers, same prefetch distance:
+      // XA(t) is requested one step later than before, together with XU(t+1).
 #pragma unroll
       for (int t = 0; t < NTC; t++) {
         double2 nu0, nu1, na0, na1;
-        if (t + 1 < NTC) {
-          nu0 = xu[(t + 1) * 128]; nu1 = xu[(t + 1) * 128 + 64];
-          na0 = xa[(t + 1) * 128]; na1 = xa[(t + 1) * 128 + 64];
-        }
-        aq_d4 Rt = Rr[t];
+        if (t + 1 < NTC) { nu0 = xu[(t + 1) * 128]; nu1 = xu[(t + 1) * 128 + 64]; }
+        if (t >= 1) { na0 = xa[t * 128]; na1 = xa[t * 128 + 64]; }
         if (do_u) {
+          aq_d4 Rt = Rr[t];
           Rt = aq_mfma(cu0.x, nd[0], Rt);
           Rt = aq_mfma(cu0.y, nd[1], Rt);
           Rt = aq_mfma(cu1.x, nd[2], Rt);
           Rt = aq_mfma(cu1.y, nd[3], Rt);
           Rr[t] = Rt;
         }
-        if (do_s) {
-          acc = aq_mfma(ca0.x, Rt[0], acc);
-          acc = aq_mfma(ca0.y, Rt[1], acc);
-          acc = aq_mfma(ca1.x, Rt[2], acc);
-          acc = aq_mfma(ca1.y, Rt[3], acc);
+        if (t >= 1) {
+          if (do_s) {
+            const aq_d4 Rp = Rr[t - 1];
+            acc = aq_mfma(ca0.x, Rp[0], acc);
+            acc = aq_mfma(ca0.y, Rp[1], acc);
+            acc = aq_mfma(ca1.x, Rp[2], acc);
+            acc = aq_mfma(ca1.y, Rp[3], acc);
+          }
+          ca0 = na0; ca1 = na1;
         }
-        if (t + 1 < NTC) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
+        if (t + 1 < NTC) { cu0 = nu0; cu1 = nu1; }
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if (do_s) {
+        const aq_d4 Rp = Rr[NTC - 1];
+        acc = aq_mfma(ca0.x, Rp[0], acc);
+        acc = aq_mfma(ca0.y, Rp[1], acc);
+        acc = aq_mfma(ca1.x, Rp[2], acc);
+        acc = aq_mfma(ca1.y, Rp[3], acc);
       }
       if (do_s) {
 #pragma unroll
