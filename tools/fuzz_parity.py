@@ -1,0 +1,57 @@
+"""Randomised parity sweep: random small shapes (ragged n, p, q; with and without missing values; with and without
+annealing) through the HIP path against the oracle.  usage: python tools/fuzz_parity.py [ncases] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import atlasqtl_amd as A
+from oracle import atlasqtl_oracle as O
+from tests.util import make_problem
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    worst = dict(elbo=0.0, mu=0.0, gam=0.0)
+    t0 = time.time()
+    for c in range(ncases):
+        n = int(rng.integers(20, 400))
+        p = int(rng.integers(12, 160))
+        q = int(rng.integers(1, 70))
+        na = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
+        anneal = [None, (1, 2, 10), (2, 3, 5), (3, 2, 4)][int(rng.integers(0, 4))]
+        prob = make_problem(n, p, q, p_act=max(1, min(8, p // 3)), prob_assoc=0.4, na_frac=na, seed=int(rng.integers(1, 10**6)),
+                            init_seed=int(rng.integers(1, 10**6)), p0=(2, 6))
+        tr = []
+        try:
+            ref = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, 1, 0.1, 300, prob["list_hyper"], prob["list_init"],
+                                                trace=tr, full_output=True)
+        except Exception as e:   # e.g. a non-monotone ELBO on a degenerate draw: both sides must agree that it fails
+            try:
+                A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, 1, 0.1, 300, 0, prob["list_hyper"], prob["list_init"],
+                                              full_output=True, debug=True)
+                print(f"case {c}: oracle raised {e!r} but the HIP path did not", flush=True)
+                sys.exit(1)
+            except Exception:
+                print(f"case {c}: n={n} p={prob['p']} q={q} na={na} anneal={anneal}: both raise", flush=True)
+                continue
+        got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, 1, 0.1, 300, 0, prob["list_hyper"], prob["list_init"],
+                                            full_output=True, debug=True)
+        lref = np.array([r["lb"] for r in tr if r["lb"] is not None])
+        e_elbo = float(np.max(np.abs(got["elbo_trace"][1] - lref) / np.abs(lref))) if lref.size else 0.0
+        e_mu = float(np.max(np.abs(got["mu_beta_vb"] - ref["mu_beta_vb"]) / np.maximum(np.abs(ref["mu_beta_vb"]), 1e-8)))
+        e_g = float(np.max(np.abs(got["gam_vb"] - ref["gam_vb"])))
+        ok = got["it"] == ref["it"] and e_elbo < 1e-8 and e_mu < 1e-6 and e_g < 1e-8
+        worst = dict(elbo=max(worst["elbo"], e_elbo), mu=max(worst["mu"], e_mu), gam=max(worst["gam"], e_g))
+        print(f"case {c}: n={n} p={prob['p']} q={q} na={na} anneal={anneal} kernel={got['core_kernel']} it={got['it']}/{ref['it']} "
+              f"elbo {e_elbo:.1e} mu {e_mu:.1e} gam {e_g:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+        if not ok:
+            sys.exit(1)
+    print(f"{ncases} cases ok in {time.time() - t0:.0f} s; worst: {worst}")
+
+
+if __name__ == "__main__":
+    main()
