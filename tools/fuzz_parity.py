@@ -12,9 +12,9 @@ from oracle import atlasqtl_oracle as O
 from tests.util import make_problem
 
 
-def main():
-    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+def run(ncases=30, seed=2024):
+    """Returns the worst errors; raises AssertionError on the first mismatch."""
+    rng = np.random.default_rng(seed)
     worst = dict(elbo=0.0, mu=0.0, gam=0.0)
     t0 = time.time()
     for c in range(ncases):
@@ -33,8 +33,7 @@ def main():
             try:
                 A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, 1, 0.1, 300, 0, prob["list_hyper"], prob["list_init"],
                                               full_output=True, debug=True)
-                print(f"case {c}: oracle raised {e!r} but the HIP path did not", flush=True)
-                sys.exit(1)
+                raise AssertionError(f"case {c}: oracle raised {e!r} but the HIP path did not")
             except Exception:
                 print(f"case {c}: n={n} p={prob['p']} q={q} na={na} anneal={anneal}: both raise", flush=True)
                 continue
@@ -48,10 +47,10 @@ def main():
         worst = dict(elbo=max(worst["elbo"], e_elbo), mu=max(worst["mu"], e_mu), gam=max(worst["gam"], e_g))
         print(f"case {c}: n={n} p={prob['p']} q={q} na={na} anneal={anneal} kernel={got['core_kernel']} it={got['it']}/{ref['it']} "
               f"elbo {e_elbo:.1e} mu {e_mu:.1e} gam {e_g:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
-        if not ok:
-            sys.exit(1)
+        assert ok, f"case {c} mismatch"
     print(f"{ncases} cases ok in {time.time() - t0:.0f} s; worst: {worst}")
+    return worst
 
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
