@@ -58,3 +58,41 @@ def test_c3_sweeps_are_monotone_and_bounded():
     assert len(lbs) >= 3 and np.all(np.diff(lbs) > 0)
     assert rs.shape == (p,) and 0 <= nb <= p * q
     assert st["core_ms"] / st["core_launches"] < 120.0          # ms per core launch; 45 measured
+
+
+def _shard_worker(rank, world, port, outdir, n, p, q, sweeps):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from atlasqtl_amd.core import VbRun
+    tiles = (q + 15) // 16
+    k0, k1 = min(q, 16 * ((tiles * rank) // world)), min(q, 16 * ((tiles * (rank + 1)) // world))
+    X, Y, lh, li = bench.build_problem(n, p, q, k0, k1, 0)
+    run = VbRun(Y, X, lh, li, (1, 2, 10), tol=1e-12, maxit=sweeps, thinned_elbo_eval=False, debug=True, device=0, q_total=q,
+                process_group=dist.group.WORLD)
+    run.run()
+    its, lbs = run.elbo_trace()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), lbs=lbs, it=run.status()["it"])
+    run.close()
+    dist.destroy_process_group()
+
+
+def test_c2_two_trait_shards_reproduce_the_single_shard_elbo(tmp_path):
+    """The q-sharded protocol at C2 size (two processes share the one GPU, payloads reduced through gloo on the host): same
+    ELBO trace as the unsharded run -- the all-reduced sums are added in a different order, nothing else differs."""
+    import socket
+    import torch.multiprocessing as mp
+    n, p, q, sweeps = 1000, 5000, 1000, 16
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path), n, p, q, sweeps), nprocs=2, join=True)
+    X, Y, lh, li = _bench_problem(n, p, q)
+    st, (its, lbs), _, _ = _run(X, Y, lh, li, q, sweeps)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["it"]) == int(r1["it"]) == st["it"] == sweeps
+    np.testing.assert_array_equal(r0["lbs"], r1["lbs"])
+    np.testing.assert_allclose(r0["lbs"], lbs, rtol=1e-10)
