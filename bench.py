@@ -232,8 +232,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_warm = None
     if args.warmup > 0:
+        sync()
+        tw = time.perf_counter()
         run.run_sweeps(args.warmup)
+        sync()
+        t_warm = time.perf_counter() - tw
     st0 = run.status()
     sync()
     t0 = time.perf_counter()
@@ -262,6 +267,8 @@ def main():
                                    f"anneal=(1,2,10) on, horseshoe global-local, sweeps {st0['it'] + 1}-{st1['it']}",
                        "n": n, "p": p, "q": q, "q_per_gpu": q_loc, "parallelism": f"trait-sharded x{world}",
                        "elbo_evals_in_timed_region": st1["n_elbo"] - st0["n_elbo"], "elbo_last": st1["lb_opt"],
+                       # the warm-up sweeps are the annealing ladder (the probit terms are evaluated twice there)
+                       "annealed_sweeps_per_s": (args.warmup / t_warm) if t_warm else None,
                        "setup_s": round(t_setup, 1)},
             "roofline": {"bound": "mfma", "kernel": {0: "aq_core_sweep_la_kernel", 1: "aq_core_sweep_kernel", 2: "aq_trait_wave_kernel",
                                                      3: "aq_core_sweep_mis_kernel"}[st1["core_kernel"]], "achieved": achieved,
