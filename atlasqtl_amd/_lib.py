@@ -77,6 +77,7 @@ SYMBOLS = {
     "aq_special_eval": (C.c_int, [C.c_int32, dp, dp, dp, C.c_int64]),
     "aq_special_eval_device": (C.c_int, [C.c_int32, dp, dp, dp, C.c_int64, C.c_int32]),
     "aq_q_approx_vec": (C.c_int, [dp, dp, C.c_int64, ip]),
+    "aq_vb_debug_raise_errflag": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None

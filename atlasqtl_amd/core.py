@@ -153,7 +153,6 @@ class VbRun:
             pr.init_seed = int(list_init["device_seed"]) & 0xFFFFFFFFFFFFFFFF
             pr.init_gam_mean = float(list_init["device_gam_mean"])
             pr.init_gam_sd = float(list_init["device_gam_sd"])
-            pr.trait_offset = int(trait_offset)
             pr.init_on_device = 0
         elif hasattr(g0, "data_ptr"):
             # torch CUDA tensors holding the p x q matrices column-major, i.e. a contiguous (q, p) tensor
@@ -182,6 +181,7 @@ class VbRun:
         pr.thinned_elbo_eval = 1 if thinned_elbo_eval else 0
         pr.debug = 1 if debug else 0
         pr.device = int(device); pr.world_size = int(self.world)
+        pr.trait_offset = int(trait_offset)
         pr.ext_reduce_main = ext_main
         pr.ext_reduce_elbo = ext_elbo
         h = C.c_void_p()
@@ -322,7 +322,9 @@ def _run_with_checkpoints(run, checkpoint_path, rate, maxit):
     """checkpoint_ / checkpoint_clean_up_ (R/utils.R:571-627, R/atlasqtl_global_local_core.R:379,388): every `rate`
     iterations write the reference's temporary output list (tmp_output_it_<it>.npz: beta_vb, gam_vb, theta_vb, zeta_vb,
     converged, it, lb_new, diff_lb, lam2_inv_vb, sig02_inv_vb) and keep only the last two; remove them all at the end.
-    Beside each, hip_state_it_<it>.npy holds the complete device state for `resume_from` (the reference cannot resume)."""
+    Beside each, hip_state_it_<it>.npy holds the complete device state for `resume_from` (the reference cannot resume);
+    they are removed as well once the run has converged (a run that is killed, or that stops at maxit, leaves its last
+    two behind: that is their use)."""
     import glob
     import os
     if not os.path.isdir(checkpoint_path):
@@ -347,28 +349,38 @@ def _run_with_checkpoints(run, checkpoint_path, rate, maxit):
                 old = os.path.join(checkpoint_path, stem)          # keep only the last two for comparison
                 if os.path.exists(old):
                     os.remove(old)
-    for f in glob.glob(os.path.join(checkpoint_path, f"tmp_output_it_*{tag}.npz")):
-        os.remove(f)
+    # checkpoint_clean_up_ (R/utils.R:614-627) leaves the directory clean; so do the resumable state files once the run
+    # has converged (after maxit without convergence the last two stay: resume_from with a larger maxit continues them)
+    pats = [f"tmp_output_it_*{tag}.npz"] + ([f"hip_state_it_*{tag}.npy"] if run.status()["converged"] else [])
+    for pat in pats:
+        for f in glob.glob(os.path.join(checkpoint_path, pat)):
+            os.remove(f)
 
 
 def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbose, list_hyper, list_init,
                                 checkpoint_path=None, trace_path=None, full_output=False, thinned_elbo_eval=True,
                                 debug=False, batch="y", device=0, process_group=None, resume_from=None,
-                                checkpoint_rate=100):
+                                checkpoint_rate=100, trait_offset=None):
     """R/atlasqtl_global_local_core.R:8-433 on the GPU.  Returns the reference's list
     (:426-428): beta_vb, gam_vb, theta_vb, zeta_vb, n, p, q, anneal, converged, it, maxit,
     tol, lb_opt, diff_lb (+ the variational parameters with full_output).
 
     shr_fac_inv is the total number of traits (R/atlasqtl.R:218); with a process group each
-    rank passes its own trait columns and shr_fac_inv = q of the whole problem."""
+    rank passes its own trait columns and shr_fac_inv = q of the whole problem.  trait_offset = global index of
+    this rank's first trait: required with a process group when the p x q initial values are drawn on the device
+    (the Philox counters are (SNP, global trait), so a sharded run reproduces the single-GPU draws)."""
     if df != 1:
         raise NotImplementedError("df != 1 is unreachable from atlasqtl() (df <- 1, R/atlasqtl.R:272)")
     if batch != "y":
         raise ValueError("Batch scheme not defined. Exit.")            # :231
     if trace_path is not None:
         raise NotImplementedError("trace_path (trace plots) is outside the accelerated path")
+    device_init = list_init.get("gam_vb") is None and list_init.get("mu_beta_vb") is None
+    if process_group is not None and device_init and trait_offset is None:
+        raise ValueError("trait_offset is required with process_group when the initial values are drawn on the device: "
+                         "without it every trait shard would start from the draws of traits 0..q_local-1")
     run = VbRun(Y, X, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval, debug, device=device,
-                q_total=int(shr_fac_inv), process_group=process_group)
+                q_total=int(shr_fac_inv), process_group=process_group, trait_offset=int(trait_offset or 0))
     try:
         if resume_from is not None:
             run.set_state(np.load(resume_from))

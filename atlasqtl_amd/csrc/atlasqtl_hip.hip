@@ -120,7 +120,7 @@ static int aq_upload_padded(double *dst, const double *src, size_t n, size_t n_p
 
 // ------------------------------------------------------------------ state ----
 struct aq_vb {
-  int n, p, q, q_total, p_pad, q_pad, n_pad, nb, ntile, NT, NW, dmode, device, world;
+  int n, p, q, q_total, p_pad, q_pad, n_pad, nb, ntile, NT, NW, dmode, device, world, trait_offset = 0;
   // hyper / control
   double A2_inv, m0, nu, rho, t02, t02_inv, shr;
   bool has_anneal;
@@ -137,7 +137,6 @@ struct aq_vb {
   double *zeta = nullptr, *tau = nullptr, *sig2b = nullptr, *log_tau = nullptr, *eta_vb = nullptr, *kappa_vb = nullptr;
   double *coef = nullptr, *inv2s = nullptr, *cst = nullptr, *sums = nullptr, *rowA = nullptr, *rowGB = nullptr;
   double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
-  int TT = 1;
   bool use_la = false;   // look-ahead kernel (aq_core_sweep_la.h)
   int NT2 = 0;           // look-ahead kernel: tiles of matrix waves 4,5,6 (NT: waves 0,1,2)
   bool use_tw = false;   // generic wave-per-trait kernel (aq_trait_wave.h): missing Y, or n beyond the MFMA kernels
@@ -179,6 +178,9 @@ struct aq_vb {
   double core_ms_acc = 0.0;
   int core_launches = 0;
   bool failed = false;
+  int fail_code = AQ_ERR_NUMERIC;   // why the handle failed (reported again by every later advance)
+  std::string fail_msg;
+  bool errflag_forced = false;   // test hook aq_vb_debug_raise_errflag
   int budget = -1;
 };
 
@@ -289,7 +291,6 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   a.c = c;
   a.p = s->p; a.q = s->q; a.p_pad = s->p_pad; a.q_pad = s->q_pad; a.n_pad = s->n_pad; a.nb = s->nb; a.ntile = s->ntile;
   a.dmode = s->dmode; a.mode = mode;
-  dim3 grid((s->ntile + s->TT - 1) / s->TT), block(s->NW * 64);
   hipEvent_t e0, e1;
   AQ_HIP(hipEventCreate(&e0));
   AQ_HIP(hipEventCreate(&e1));
@@ -339,16 +340,9 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     } else {
       AQ_TRY(launch(0, s->ntile, 0, s->nb, 0, 0));
     }
-  } else
-#define AQ_CASE(NT_, NW_, TT_)                                                             \
-  if (s->NT == NT_ && s->NW == NW_ && s->TT == TT_) {                                      \
-    hipLaunchKernelGGL((aq_core_sweep_kernel<NT_, NW_, TT_>), grid, block, 0, 0, a);       \
-  } else
-  AQ_CASE(2, 4, 1) AQ_CASE(4, 4, 1) AQ_CASE(8, 4, 1) AQ_CASE(16, 4, 1) AQ_CASE(16, 8, 1)
-  AQ_CASE(2, 4, 3) AQ_CASE(4, 4, 3) AQ_CASE(8, 4, 3) AQ_CASE(16, 4, 3) {
-    return aq_fail(AQ_ERR_UNSUPPORTED, "no core kernel instantiation for this n");
+  } else {
+    return aq_fail(AQ_ERR_UNSUPPORTED, "no core kernel selected for this problem");
   }
-#undef AQ_CASE
   AQ_HIP(hipEventRecord(e1, 0));
   AQ_HIP(hipGetLastError());
 #if AQ_DIAG & 8
@@ -423,6 +417,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   aq_vb *s = new aq_vb();
   s->device = pr->device;
   s->n = pr->n; s->p = pr->p; s->q = pr->q; s->q_total = pr->q_total; s->world = pr->world_size;
+  s->trait_offset = pr->trait_offset;
   s->p_pad = (pr->p + 15) / 16 * 16;
   s->q_pad = (pr->q + 15) / 16 * 16;
   s->nb = s->p_pad / 16;
@@ -432,14 +427,8 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     if (hipGetDeviceProperties(&prop, pr->device) == hipSuccess && prop.multiProcessorCount > 0) s->ncu = prop.multiProcessorCount;
     if (const char *e = getenv("AQ_NCU")) s->ncu = atoi(e) > 0 ? atoi(e) : s->ncu;
   }
-  // residual tile geometry: n_pad = 16 * NT * NW samples
-  if (pr->n <= 128) { s->NT = 2; s->NW = 4; }
-  else if (pr->n <= 256) { s->NT = 4; s->NW = 4; }
-  else if (pr->n <= 512) { s->NT = 8; s->NW = 4; }
-  else if (pr->n <= 1024) { s->NT = 16; s->NW = 4; }
-  else { s->NT = 16; s->NW = 8; }   // n <= 2048; larger n runs on the generic kernel below
   {
-    // default: look-ahead kernel; AQ_KERNEL=1 selects the two-barrier MFMA kernel, AQ_KERNEL=2 the generic one
+    // default: look-ahead kernel (complete Y, n <= 1056); AQ_KERNEL=2 forces the generic wave-per-trait kernel
     const char *ek = getenv("AQ_KERNEL");
     // missing values: masked blocked MFMA kernel while n fits 8 waves x 16 residual tiles and no trait misses more
     // than AQ_MIS_MMAX samples; otherwise (and with AQ_KERNEL=2) the generic kernel
@@ -486,8 +475,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       const int per_lane = (pr->n + 64 * s->WPT - 1) / (64 * s->WPT);
       s->NE = per_lane <= 4 ? 4 : per_lane <= 8 ? 8 : per_lane <= 16 ? 16 : per_lane <= 32 ? 32 : 40;
     }
-    bool want_la = !s->use_tw && !s->use_mis && !(ek && atoi(ek) == 1);
-    if (want_la && pr->n <= 1024) {
+    if (!s->use_tw && !s->use_mis) {
       // 6 matrix waves x NT residual tiles each (n padded to 96 NT samples) + the recurrence wave
       s->use_la = true;
       const int ntiles = (pr->n + 15) / 16;
@@ -497,8 +485,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       s->NT = (per_simd + 1) / 2;
       s->NT2 = per_simd - s->NT;
       if (s->NT2 < 1) s->NT2 = s->NT;
-      if (s->NT > 11) { s->use_la = false; s->NT = 16; s->NW = 4; }   // falls back to the two-barrier kernel
-      else s->n_pad = 16 * 3 * (s->NT + s->NT2);
+      s->n_pad = 16 * 3 * (s->NT + s->NT2);   // n <= 1056 -> NT <= 11
       // more trait tiles than CUs: chained SNP segments even out the last round (3 rounds -> ~2.5 for 625 tiles)
       if (s->ntile > s->ncu) {
         double best = 1e30;
@@ -528,7 +515,6 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     if (s->chain > s->nb) s->chain = s->nb;
     if (s->chain > 32) s->chain = 32;
   }
-  if (!s->use_la) s->n_pad = 16 * s->NT * s->NW;
   if (s->use_mis) { s->n_pad = 128 * s->NT * s->misC; s->NR = s->n_pad + 8; }
   if (s->use_tw) {
     s->n_pad = 64 * s->NE * s->WPT;
@@ -536,11 +522,6 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     s->tw_ns = 4;
     while (s->tw_ns > 1 && (size_t)(s->tw_ns * s->n_pad + 8 * 256 + 32) * sizeof(double) > 150 * 1024) s->tw_ns /= 2;
   }
-  // trait tiles per workgroup: 1 (two workgroups per CU) unless that would need a second round of workgroups
-  s->TT = 1;
-  if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 3 ? 3 : 1;
-  else if (s->NW == 4 && s->ntile > 512) s->TT = 3;
-  if (s->NW != 4 || s->use_la || s->use_mis) s->TT = 1;
   int rc = aq_probe_dmode(&s->dmode);
   if (rc != AQ_OK) { delete s; return rc; }
 
@@ -793,13 +774,19 @@ static int aq_elbo_local(aq_vb *s) {
   return AQ_OK;
 }
 
+// Bounded waits inside the sweep kernels (a chained segment waiting for its predecessor, a sample part waiting for its
+// partners' partial S) raise errflag when they expire: the results of that launch are invalid.  Polled wherever results
+// leave the library: ELBO evaluation, end of a run, status, state and result getters.
 static int aq_check_chain_error(aq_vb *s) {
-  if (s->chain <= 1 || !s->errflag) return AQ_OK;
+  if (!s->errflag || (s->chain <= 1 && s->misC <= 1 && !s->errflag_forced)) return AQ_OK;
   int f = 0;
   AQ_HIP(hipMemcpy(&f, s->errflag, sizeof(int), hipMemcpyDeviceToHost));
   if (f != 0) {
     s->failed = true;
-    return aq_fail(AQ_ERR_DEVICE, "chained core sweep: a bounded wait on a tile's previous SNP segment expired (results invalid; set AQ_CHAIN=0)");
+    s->fail_code = AQ_ERR_DEVICE;
+    s->fail_msg = s->misC > 1 ? "core sweep: a bounded wait on a partner workgroup's partial sums expired (results invalid)"
+                              : "chained core sweep: a bounded wait on a tile's previous SNP segment expired (results invalid; set AQ_CHAIN=0)";
+    return aq_fail(AQ_ERR_DEVICE, s->fail_msg);
   }
   return AQ_OK;
 }
@@ -822,7 +809,7 @@ static bool aq_all_equal_1(double c) { return std::fabs(c - 1.0) < 1.5e-8; }
 
 // One step of the state machine.  stop_after_sweeps < 0: unlimited.
 static int aq_advance_impl(aq_vb *s, int *sweeps_budget) {
-  if (s->failed) return -aq_fail(AQ_ERR_NUMERIC, "handle is in a failed state");
+  if (s->failed) return -aq_fail(s->fail_code, "handle is in a failed state: " + s->fail_msg);
   AQ_HIP(hipSetDevice(s->device));
   for (;;) {
     switch (s->phase) {
@@ -879,9 +866,11 @@ static int aq_advance_impl(aq_vb *s, int *sweeps_budget) {
         const double eps = std::sqrt(std::numeric_limits<double>::epsilon());      // :85
         if (s->debug && lb + eps < s->lb_old) {                                    // :359-360
           s->failed = true;
+          s->fail_code = AQ_ERR_NUMERIC;
           char buf[256];
           std::snprintf(buf, sizeof(buf), "ELBO not increasing monotonically. Exit. (it=%d, lb_old=%.17g, lb_new=%.17g)", s->it,
                         s->lb_old, lb);
+          s->fail_msg = buf;
           return -aq_fail(AQ_ERR_NUMERIC, buf);
         }
         double diff = std::fabs(lb - s->lb_old);                                   // :362
@@ -921,7 +910,7 @@ static int aq_run_impl(aq_vb *s, int *budget) {
     if (rc == AQ_VB_DONE) break;
   }
   AQ_HIP(hipDeviceSynchronize());
-  return AQ_OK;
+  return aq_check_chain_error(s);
 }
 extern "C" int aq_vb_run(aq_vb_handle h) {
   if (!h) return aq_fail(AQ_ERR_ARG, "NULL handle");
@@ -1022,12 +1011,13 @@ extern "C" int aq_vb_hotspot_sizes(aq_vb_handle s, double thres, int32_t fdr_adj
 // sweep reads (gam, mu, the incrementally updated residual, p- and q-vectors, column sums, AqScalars).  A, b and the row
 // sums of the pre-pass are not stored: the next sweep recomputes them from theta and zeta (same kernel, same bits).
 struct AqStateHeader {
-  uint64_t magic;        // "AQVBST01"
+  uint64_t magic;        // "AQVBST02"
   int32_t n, p, q, q_total, p_pad, q_pad, n_pad, core_kernel;
   int32_t it, converged, annealing, ind_batch_conv, batch_conv, failed, n_trace, has_missing;
+  int32_t trait_offset, reserved;   // which trait shard of a q-sharded run the state belongs to
   double c, c_s, sig2_zeta, lb_new, lb_old;
 };
-static const uint64_t AQ_STATE_MAGIC = 0x31305453425651ull | ((uint64_t)'A' << 56);
+static const uint64_t AQ_STATE_MAGIC = 0x32305453425651ull | ((uint64_t)'A' << 56);
 
 struct AqStateSeg { void *ptr; size_t bytes; };
 static std::vector<AqStateSeg> aq_state_segments(aq_vb *s) {
@@ -1040,7 +1030,7 @@ static std::vector<AqStateSeg> aq_state_segments(aq_vb *s) {
       {s->coef, Q}, {s->inv2s, Q}, {s->cst, Q}, {s->sums, 6 * Q}, {s->sc, sizeof(AqScalars)}};
   return v;
 }
-static int aq_core_kernel_id(const aq_vb *s) { return s->use_mis ? 3 : s->use_tw ? 2 : s->use_la ? 0 : 1; }
+static int aq_core_kernel_id(const aq_vb *s) { return s->use_mis ? 3 : s->use_tw ? 2 : 0; }
 
 extern "C" int64_t aq_vb_state_bytes(aq_vb_handle s) {
   if (!s) return -1;
@@ -1060,7 +1050,7 @@ extern "C" int aq_vb_get_state(aq_vb_handle s, void *buf, int64_t cap) {
   std::memset(&h, 0, sizeof(h));
   h.magic = AQ_STATE_MAGIC;
   h.n = s->n; h.p = s->p; h.q = s->q; h.q_total = s->q_total; h.p_pad = s->p_pad; h.q_pad = s->q_pad; h.n_pad = s->n_pad;
-  h.core_kernel = aq_core_kernel_id(s);
+  h.core_kernel = aq_core_kernel_id(s); h.trait_offset = s->trait_offset;
   h.it = s->it; h.converged = s->converged; h.annealing = s->annealing; h.ind_batch_conv = s->ind_batch_conv;
   h.batch_conv = s->batch_conv; h.failed = s->failed; h.n_trace = (int32_t)s->trace_it.size(); h.has_missing = s->has_missing;
   h.c = s->c; h.c_s = s->c_s; h.sig2_zeta = s->sig2_zeta; h.lb_new = s->lb_new; h.lb_old = s->lb_old;
@@ -1085,6 +1075,8 @@ extern "C" int aq_vb_set_state(aq_vb_handle s, const void *buf, int64_t len) {
   if (h.n != s->n || h.p != s->p || h.q != s->q || h.q_total != s->q_total || h.p_pad != s->p_pad || h.q_pad != s->q_pad ||
       h.n_pad != s->n_pad || h.core_kernel != aq_core_kernel_id(s) || h.has_missing != (int)s->has_missing)
     return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state was saved for a different problem shape or kernel geometry");
+  if (h.trait_offset != s->trait_offset)
+    return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state belongs to another trait shard (trait_offset differs)");
   size_t need = sizeof(h) + (size_t)h.n_trace * (sizeof(int32_t) + sizeof(double));
   for (auto &g : aq_state_segments(s)) need += g.bytes;
   if (h.n_trace < 0 || (int64_t)need != len) return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: state size mismatch");
@@ -1145,6 +1137,7 @@ extern "C" int aq_vb_get_result(aq_vb_handle s, double *beta_vb, double *gam_vb,
   if (!s) return aq_fail(AQ_ERR_ARG, "NULL handle");
   AQ_HIP(hipSetDevice(s->device));
   AQ_HIP(hipDeviceSynchronize());
+  AQ_TRY(aq_check_chain_error(s));
   size_t pq = (size_t)s->p * s->q;
   if (beta_vb || gam_vb || mu_beta_vb) {
     double *stage;
@@ -1276,6 +1269,15 @@ extern "C" int aq_core_dual_mis_loop(const double *cp_X, const double *const *cp
 }
 
 // ------------------------------------------------------------- test hooks ----
+extern "C" int aq_vb_debug_raise_errflag(aq_vb_handle s) {
+  if (!s || !s->errflag) return aq_fail(AQ_ERR_ARG, "NULL handle");
+  AQ_HIP(hipSetDevice(s->device));
+  int one = 1;
+  AQ_HIP(hipMemcpy(s->errflag, &one, sizeof(int), hipMemcpyHostToDevice));
+  s->errflag_forced = true;
+  return AQ_OK;
+}
+
 // one element of the test hook, compiled for host and device from the same header the kernels use
 __host__ __device__ static inline bool aq_special_one(int which, double x, double x2, double *out) {
   double a_, b_, c_, d_;

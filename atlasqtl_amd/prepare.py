@@ -109,6 +109,11 @@ def scale_columns(X):
     X = np.asarray(X, dtype=np.float64)
     n = X.shape[0]
     mean = X.mean(axis=0)
+    mean = mean + (X - mean).mean(axis=0)          # second pass: R's colMeans accumulates in long double
+    # a constant column has mean == its value exactly in R (0/0 = NaN below); numpy's pairwise sum can be an ulp off
+    # for non-dyadic values (0.1, 1/3), which would leave a finite +-0.99 column behind
+    const = X.max(axis=0) == X.min(axis=0)
+    mean = np.where(const, X[0], mean)
     Xc = X - mean
     sd = np.sqrt((Xc ** 2).sum(axis=0) / (n - 1))
     with np.errstate(invalid="ignore", divide="ignore"):

@@ -160,8 +160,8 @@ typedef struct aq_vb_status {
   int32_t core_launches;
   double sig02_inv_vb, sig2_inv_vb;
   int32_t lentz_iters;   /* shared Lentz iteration count of the last non-annealed sweep */
-  int32_t core_kernel;   /* which core sweep kernel this handle runs: 0 look-ahead MFMA, 1 two-barrier MFMA,
-                            2 generic wave-per-trait (VALU), 3 masked MFMA (missing values in Y) */
+  int32_t core_kernel;   /* which core sweep kernel this handle runs: 0 look-ahead MFMA (complete Y, n <= 1056),
+                            2 generic wave-per-trait (VALU), 3 masked MFMA (missing values in Y, or n > 1056) */
 } aq_vb_status;
 int aq_vb_get_status(aq_vb_handle h, aq_vb_status *st);
 
@@ -213,6 +213,10 @@ int aq_vb_set_state(aq_vb_handle h, const void *buf, int64_t len);
  * ---------------------------------------------------------------------------------------- */
 int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len);
 int aq_special_eval_device(int32_t which, const double *x, const double *x2, double *out, int64_t len, int32_t device);
+/* Test hook: raises the device-side flag that a bounded in-kernel wait sets when it expires (a chained SNP segment
+ * waiting for its predecessor, a sample part waiting for its partners); every later aq_vb_run / aq_vb_get_status /
+ * aq_vb_get_state / aq_vb_get_result on the handle must then fail with AQ_ERR_DEVICE. */
+int aq_vb_debug_raise_errflag(aq_vb_handle h);
 /* exp(x) E1(x) for a vector with the reference's shared Lentz stopping rule (R/utils.R:380-423);
  * host evaluation; writes the shared iteration count to *iters. */
 int aq_q_approx_vec(const double *x, double *out, int64_t len, int32_t *iters);

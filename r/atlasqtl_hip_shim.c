@@ -91,7 +91,10 @@ SEXP atlasqtl_hip_vb_run(SEXP Y, SEXP X, SEXP list_hyper, SEXP list_init, SEXP a
     error("%s", aq_last_error());
   }
   aq_vb_status st;
-  aq_vb_get_status(h, &st);
+  if (aq_vb_get_status(h, &st) != AQ_OK) {          /* e.g. a bounded in-kernel wait expired: results invalid */
+    aq_vb_destroy(h);
+    error("atlasqtl (HIP): %s", aq_last_error());
+  }
   SEXP beta = PROTECT(allocMatrix(REALSXP, pr.p, pr.q)), gam = PROTECT(allocMatrix(REALSXP, pr.p, pr.q));
   SEXP theta = PROTECT(allocVector(REALSXP, pr.p)), zeta = PROTECT(allocVector(REALSXP, pr.q));
   int rc = aq_vb_get_result(h, REAL(beta), REAL(gam), NULL, REAL(theta), REAL(zeta), NULL, NULL, NULL, NULL);

@@ -152,11 +152,17 @@ def test_checkpoint_path_and_resume(tmp_path):
     got = A.atlasqtl_global_local_core_(*args, full_output=True, checkpoint_path=str(tmp_path), checkpoint_rate=10)
     assert got["it"] == ref["it"] > 30
     np.testing.assert_array_equal(got["gam_vb"], ref["gam_vb"])
+    assert os.listdir(tmp_path) == []                                         # converged: checkpoint_clean_up_, states too
+    # stopped at maxit before convergence: the last two state files stay and a later call resumes from them
+    short = list(args)
+    short[6] = 25                                                             # maxit
+    part = A.atlasqtl_global_local_core_(*short, full_output=True, checkpoint_path=str(tmp_path), checkpoint_rate=10)
+    assert part["it"] == 25 and not part["converged"]
     files = sorted(os.listdir(tmp_path))
-    assert not [f for f in files if f.startswith("tmp_output_it_")]          # checkpoint_clean_up_
+    assert not [f for f in files if f.startswith("tmp_output_it_")]
     states = [f for f in files if f.startswith("hip_state_it_")]
-    assert len(states) == 2                                                   # the last two
-    again = A.atlasqtl_global_local_core_(*args, full_output=True, resume_from=os.path.join(tmp_path, states[0]))
+    assert states == ["hip_state_it_10.npy", "hip_state_it_20.npy"]           # the last two
+    again = A.atlasqtl_global_local_core_(*args, full_output=True, resume_from=os.path.join(tmp_path, states[1]))
     assert again["it"] == ref["it"]
     np.testing.assert_array_equal(again["gam_vb"], ref["gam_vb"])
     np.testing.assert_array_equal(again["elbo_trace"][1], ref["elbo_trace"][1])
@@ -217,6 +223,74 @@ def test_device_generated_init_does_not_depend_on_sharding():
     g_sh = shard.result()["gam_vb"]
     shard.close()
     np.testing.assert_array_equal(g_sh, g_full[:, k0:])
+
+
+def _sharded_device_init_worker(rank, world, port, outdir):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import atlasqtl_amd as A
+    from tests.util import make_problem
+    prob = make_problem(200, 130, 49, p_act=10, prob_assoc=0.3)
+    k0, k1 = (0, 32) if rank == 0 else (32, 49)
+    lh, li = dict(prob["list_hyper"]), _device_init_list(prob)
+    for k in ("eta", "kappa", "n0"):
+        lh[k] = np.asarray(lh[k])[k0:k1]
+    for k in ("sig2_beta_vb", "tau_vb", "zeta_vb"):
+        li[k] = np.asarray(li[k])[k0:k1]
+    args = (prob["Y"][:, k0:k1], prob["X"], 49, (1, 2, 10), 1, 0.1, 1000, 0, lh, li)
+    if rank == 0:   # without the offset the shards would silently all start from the draws of traits 0..q_local-1
+        with pytest.raises(ValueError, match="trait_offset is required"):
+            A.atlasqtl_global_local_core_(*args, process_group=dist.group.WORLD)
+    out = A.atlasqtl_global_local_core_(*args, full_output=True, debug=True, process_group=dist.group.WORLD, trait_offset=k0)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), it=out["it"], lb=out["elbo_trace"][1], gam=out["gam_vb"], mu=out["mu_beta_vb"])
+    dist.destroy_process_group()
+
+
+def test_sharded_core_function_with_device_init_reproduces_single_gpu(tmp_path):
+    """atlasqtl_global_local_core_(process_group=..., trait_offset=...) with device-drawn initial values: two trait shards
+    (two processes on the one GPU, gloo-staged payloads) reproduce the single-process run -- the Philox counters are
+    (SNP, GLOBAL trait)."""
+    import socket
+    import torch.multiprocessing as mp
+    import atlasqtl_amd as A
+    from tests.util import make_problem
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_sharded_device_init_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    prob = make_problem(200, 130, 49, p_act=10, prob_assoc=0.3)
+    one = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 49, (1, 2, 10), 1, 0.1, 1000, 0, prob["list_hyper"],
+                                        _device_init_list(prob), full_output=True, debug=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["it"]) == int(r1["it"]) == one["it"]
+    np.testing.assert_allclose(r0["lb"], one["elbo_trace"][1], rtol=1e-10)
+    np.testing.assert_allclose(np.concatenate([r0["mu"], r1["mu"]], axis=1), one["mu_beta_vb"], rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(np.concatenate([r0["gam"], r1["gam"]], axis=1), one["gam_vb"], atol=1e-10)
+
+
+@pytest.mark.parametrize("env", [{"AQ_MIS_C": "3"}, {"AQ_CHAIN": "4"}])
+def test_expired_in_kernel_wait_is_reported_everywhere(env, monkeypatch):
+    """A bounded wait that expires inside a sweep kernel (sample split: a partner's partial S; chained segments: the
+    previous segment's residual) raises a device flag: results are invalid.  The flag is forced through the test hook;
+    run, status, state and result getters must all report AQ_ERR_DEVICE afterwards."""
+    import ctypes as C
+    from atlasqtl_amd._lib import AtlasqtlHipError, lib
+    from tests.util import make_problem
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    na = 0.04 if "AQ_MIS_C" in env else 0.0
+    prob = make_problem(300, 130, 49, p_act=8, prob_assoc=0.3, na_frac=na)
+    run = _vbrun(prob)
+    run.run_sweeps(3)
+    assert run.status()["core_kernel"] == (3 if na else 0)
+    assert lib().aq_vb_debug_raise_errflag(run.h) == 0
+    for call in (run.status, run.get_state, run.result, lambda: run.run_sweeps(1)):
+        with pytest.raises(AtlasqtlHipError, match=r"\[2\].*bounded wait"):
+            call()
+    run.close()
 
 
 def test_atlasqtl_with_device_init_converges():

@@ -22,6 +22,21 @@ def test_scale_and_removals():
     np.testing.assert_allclose(d["Y"].mean(0), 0, atol=1e-14)
 
 
+@pytest.mark.parametrize("val", [0.1, 0.3, 1.0 / 3.0, 2.7])
+@pytest.mark.parametrize("n", [50, 333, 1000])
+def test_constant_non_dyadic_column_is_removed(val, n):
+    """R's scale() centres a constant column to exactly 0 (long-double colMeans) -> 0/0 = NaN -> rm_constant_ drops it
+    (R/utils.R:276-302).  A pairwise mean that is one ulp off would leave a finite +-0.99 column behind."""
+    rng = np.random.default_rng(n)
+    X = rng.binomial(2, 0.3, size=(n, 5)).astype(float)
+    X[:, 2] = val
+    Xs = P.scale_columns(X)
+    assert np.isnan(Xs[:, 2]).all()
+    d = P.prepare_data_(rng.normal(size=(n, 3)), X, 0.1, 1000, None, 0, None, None)
+    assert list(np.where(d["bool_rmvd_x"])[0]) == [2]
+    np.testing.assert_allclose((d["X"] ** 2).sum(0), n - 1.0)
+
+
 def test_input_guards():
     rng = np.random.default_rng(0)
     X = rng.normal(size=(40, 5)); Y = rng.normal(size=(40, 3))

@@ -26,19 +26,23 @@ def run(ncases=30, seed=2024):
         prob = make_problem(n, p, q, p_act=max(1, min(8, p // 3)), prob_assoc=0.4, na_frac=na, seed=int(rng.integers(1, 10**6)),
                             init_seed=int(rng.integers(1, 10**6)), p0=(2, 6))
         tr = []
+        args_ref = (prob["Y"], prob["X"], q, anneal, 1, 0.1, 300, prob["list_hyper"], prob["list_init"])
+        args_hip = (prob["Y"], prob["X"], q, anneal, 1, 0.1, 300, 0, prob["list_hyper"], prob["list_init"])
+        ref_exc = got_exc = ref = got = None
         try:
-            ref = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, 1, 0.1, 300, prob["list_hyper"], prob["list_init"],
-                                                trace=tr, full_output=True)
-        except Exception as e:   # e.g. a non-monotone ELBO on a degenerate draw: both sides must agree that it fails
-            try:
-                A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, 1, 0.1, 300, 0, prob["list_hyper"], prob["list_init"],
-                                              full_output=True, debug=True)
-                raise AssertionError(f"case {c}: oracle raised {e!r} but the HIP path did not")
-            except Exception:
-                print(f"case {c}: n={n} p={prob['p']} q={q} na={na} anneal={anneal}: both raise", flush=True)
-                continue
-        got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, 1, 0.1, 300, 0, prob["list_hyper"], prob["list_init"],
-                                            full_output=True, debug=True)
+            ref = O.atlasqtl_global_local_core_(*args_ref, trace=tr, full_output=True, debug=True)
+        except Exception as e:   # e.g. a non-monotone ELBO on a degenerate draw: both sides must then fail the same way
+            ref_exc = e
+        try:
+            got = A.atlasqtl_global_local_core_(*args_hip, full_output=True, debug=True)
+        except Exception as e:
+            got_exc = e
+        if ref_exc is not None or got_exc is not None:
+            both = ref_exc is not None and got_exc is not None
+            same = both and ("monotonically" in str(ref_exc)) == ("monotonically" in str(got_exc))
+            assert same, f"case {c}: one-sided or different failure: oracle {ref_exc!r}, HIP {got_exc!r}"
+            print(f"case {c}: n={n} p={prob['p']} q={q} na={na} anneal={anneal}: both raise ({got_exc})", flush=True)
+            continue
         lref = np.array([r["lb"] for r in tr if r["lb"] is not None])
         e_elbo = float(np.max(np.abs(got["elbo_trace"][1] - lref) / np.abs(lref))) if lref.size else 0.0
         e_mu = float(np.max(np.abs(got["mu_beta_vb"] - ref["mu_beta_vb"]) / np.maximum(np.abs(ref["mu_beta_vb"]), 1e-8)))
