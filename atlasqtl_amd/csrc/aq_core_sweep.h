@@ -26,10 +26,6 @@
 #include <hip/hip_runtime.h>
 #include "aq_special.h"
 
-#ifndef AQ_DIAG
-#define AQ_DIAG 0      // timing diagnostics only (wrong results): 1 = skip the sequential pass, 2 = skip the MFMAs, 4 = no probit math in the helper wave, 8 = record per-phase time stamps of workgroup 0 into AqCoreArgs::dbg
-#endif
-
 typedef double aq_d4 __attribute__((ext_vector_type(4)));
 
 struct AqCoreArgs {
@@ -53,13 +49,11 @@ struct AqCoreArgs {
   int p_pad, q_pad, n_pad, nb, ntile;
   int dmode;             // f64 MFMA D layout: 0 -> row = (l>>4) + 4*reg, 1 -> row = 4*(l>>4) + reg
   int mode;              // 0 = full sweep, 1 = init: R -= X (gam*mu) only
-  int tile_first;        // look-ahead kernel: first trait tile of this launch
-  int b_begin, b_end;    // look-ahead kernel: SNP blocks [b_begin, b_end) handled by this launch (one segment)
-  int sums_slot;         // per-segment slot of the column sums: sums[slot][5][q_pad]
-  int nseg;              // > 1: chained-segment launch, block s*ntile + k = SNP segment s of trait tile k
-  int *done;             // chained segments: done[tile] = number of that tile's segments already finished
+  int nseg;              // > 1: chained-segment launch, workgroup s*nwg + k = SNP segment s of trait-tile group k (column sums of
+                         // segment s go to sums[s][5][q_pad])
+  int stagger;           // look-ahead kernel: matrix waves 4-6 start a phase when their SIMD partner has issued this many tiles (0 = off)
+  int *done;             // chained segments: done[group] = number of that group's segments already finished
   int *errflag;          // set when a bounded wait on done[] expires (results invalid, reported to the host)
-  long long *dbg;        // AQ_DIAG & 8 only: per-phase s_memtime stamps of workgroup 0 (tools/dev_check.py phases)
   const double *theta;   // look-ahead kernel (fused pre-pass): theta_vb [p_pad], zeta_vb [q_pad] of this sweep
   const double *zeta;
   double sqrt_c;         // annealing: the Mills ratios are taken at sqrt(c) (theta_j + zeta_k), R/update_vb.R:219-224

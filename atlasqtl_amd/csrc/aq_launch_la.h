@@ -1,0 +1,11 @@
+// aq_launch_la.h -- launch dispatch of the look-ahead sweep kernel (aq_core_sweep_la.h).  The template instances are
+// compiled in two translation units (aq_launch_la1.hip: one trait tile per workgroup, aq_launch_la2.hip: two) so that
+// the library builds in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "aq_core_sweep.h"
+
+// Launches aq_core_sweep_la_kernel<NT, NT2, seg, TT> on `grid` workgroups of 512 threads.  Returns 0, or -1 when there is
+// no instantiation for (NT, NT2): NT in 1..11, NT2 in {NT, NT - 1}.
+int aq_la_launch_tt1(int NT, int NT2, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a);
+int aq_la_launch_tt2(int NT, int NT2, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a);

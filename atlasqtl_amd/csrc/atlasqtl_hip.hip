@@ -14,7 +14,7 @@
 
 #include "../../include/atlasqtl_hip.h"
 #include "aq_core_sweep.h"
-#include "aq_core_sweep_la.h"
+#include "aq_launch_la.h"
 #include "aq_gram_loop.h"
 #include "aq_special.h"
 #include "aq_trait_wave.h"
@@ -138,6 +138,8 @@ struct aq_vb {
   double *coef = nullptr, *inv2s = nullptr, *cst = nullptr, *sums = nullptr, *rowA = nullptr, *rowGB = nullptr;
   double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
   bool use_la = false;   // look-ahead kernel (aq_core_sweep_la.h)
+  int TT = 1;            // look-ahead kernel: 16-trait tiles per workgroup (2 when there are enough tiles to fill the chip)
+  int stagger = 0;       // look-ahead kernel: tile at which a matrix wave releases its SIMD partner into the phase (0 = off)
   int NT2 = 0;           // look-ahead kernel: tiles of matrix waves 4,5,6 (NT: waves 0,1,2)
   bool use_tw = false;   // generic wave-per-trait kernel (aq_trait_wave.h): missing Y, or n beyond the MFMA kernels
   int NE = 0;            // samples per lane of the generic kernel
@@ -278,12 +280,6 @@ static int aq_launch_mis(aq_vb *s, int mode, double c) {
 static int aq_launch_core(aq_vb *s, int mode, double c) {
   AqCoreArgs a;
   a.XA = s->XA; a.XU = s->XU; a.G = s->G; a.Gx = s->Gx; a.R = s->R; a.gam = s->gam; a.mu = s->mu;
-  a.dbg = nullptr;
-#if AQ_DIAG & 8
-  static long long *dbg_buf = nullptr;
-  if (!dbg_buf) { AQ_HIP(hipMalloc((void **)&dbg_buf, 256 * 16 * 3 * sizeof(long long))); AQ_HIP(hipMemset(dbg_buf, 0, 256 * 16 * 3 * sizeof(long long))); }
-  a.dbg = dbg_buf;
-#endif
   a.theta = s->theta; a.zeta = s->zeta; a.sqrt_c = std::sqrt(c);
   a.c_is_one = std::fabs(c - 1.0) < 1.5e-8 ? 1 : 0;   // isTRUE(all.equal(c, 1)), R/update_vb.R:219
   a.Aarr = s->Aarr; a.Barr = s->Barr; a.coef = s->coef; a.inv2s = s->inv2s; a.cst = s->cst; a.sig2b = s->sig2b;
@@ -300,64 +296,22 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   } else if (s->use_tw) {
     AQ_TRY(aq_launch_tw(s, mode, c));
   } else if (s->use_la) {
-    dim3 blockl(8 * 64);
-    a.tile_first = 0; a.b_begin = 0; a.b_end = s->nb; a.sums_slot = 0;
-    a.nseg = 1; a.done = s->done; a.errflag = s->errflag;
-    auto launch = [&](int t_lo, int t_hi, int b0, int b1, int slot, hipStream_t st) -> int {
-      if (t_hi <= t_lo || b1 <= b0) return AQ_OK;
-      AqCoreArgs b = a;
-      b.tile_first = t_lo; b.b_begin = b0; b.b_end = b1; b.sums_slot = slot;
-      dim3 gridl(t_hi - t_lo);
-#define AQ_LA(NT_)                                                                             \
-  if (s->NT == NT_ && s->NT2 == NT_) {                                                         \
-    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, NT_, false>), gridl, blockl, 0, st, b);   \
-  } else if (s->NT == NT_ && s->NT2 == NT_ - 1 && NT_ > 1) {                                   \
-    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, (NT_ > 1 ? NT_ - 1 : 1), false>), gridl, blockl, 0, st, b); \
-  } else
-      AQ_LA(1) AQ_LA(2) AQ_LA(3) AQ_LA(4) AQ_LA(5) AQ_LA(6) AQ_LA(7) AQ_LA(8) AQ_LA(9) AQ_LA(10) AQ_LA(11) {
-        return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
-      }
-#undef AQ_LA
-      return AQ_OK;
-    };
-    if (mode == 0 && s->chain > 1) {
-      // chained-segment launch: chain * ntile workgroups, block s*ntile + k = segment s of tile k
-      AQ_HIP(hipMemsetAsync(s->done, 0, (size_t)s->ntile * sizeof(int), 0));
-      AqCoreArgs b = a;
-      b.nseg = s->chain;
-      dim3 gridc((unsigned)((long long)s->chain * s->ntile));
-#define AQ_LAC(NT_)                                                                            \
-  if (s->NT == NT_ && s->NT2 == NT_) {                                                         \
-    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, NT_, true>), gridc, blockl, 0, 0, b);     \
-  } else if (s->NT == NT_ && s->NT2 == NT_ - 1 && NT_ > 1) {                                   \
-    hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT_, (NT_ > 1 ? NT_ - 1 : 1), true>), gridc, blockl, 0, 0, b); \
-  } else
-      AQ_LAC(1) AQ_LAC(2) AQ_LAC(3) AQ_LAC(4) AQ_LAC(5) AQ_LAC(6) AQ_LAC(7) AQ_LAC(8) AQ_LAC(9) AQ_LAC(10) AQ_LAC(11) {
-        return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
-      }
-#undef AQ_LAC
+    const unsigned nwg = (unsigned)(s->ntile / s->TT);
+    a.done = s->done; a.errflag = s->errflag; a.stagger = s->stagger;
+    const bool chained = (mode == 0 && s->chain > 1);
+    a.nseg = chained ? s->chain : 1;
+    if (chained) AQ_HIP(hipMemsetAsync(s->done, 0, (size_t)s->ntile * sizeof(int), 0));
+    // chained-segment launch: chain * nwg workgroups, workgroup s*nwg + k = SNP segment s of trait-tile group k
+    const unsigned grid = chained ? (unsigned)((long long)s->chain * nwg) : nwg;
+    int lrc = s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
+    if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
+    if (chained)
       hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
-    } else {
-      AQ_TRY(launch(0, s->ntile, 0, s->nb, 0, 0));
-    }
   } else {
     return aq_fail(AQ_ERR_UNSUPPORTED, "no core kernel selected for this problem");
   }
   AQ_HIP(hipEventRecord(e1, 0));
   AQ_HIP(hipGetLastError());
-#if AQ_DIAG & 8
-  if (mode == 0 && getenv("AQ_DBG_DUMP") && s->it == 15) {
-    AQ_HIP(hipDeviceSynchronize());
-    std::vector<long long> h(256 * 16 * 3);
-    AQ_HIP(hipMemcpy(h.data(), a.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-    FILE *f = fopen(getenv("AQ_DBG_DUMP"), "w");
-    if (f) {
-      for (int b = 0; b < 256; b++)
-        for (int w = 0; w < 8; w++) fprintf(f, "%d %d %lld %lld %lld\n", b, w, h[(b * 16 + w) * 3], h[(b * 16 + w) * 3 + 1], h[(b * 16 + w) * 3 + 2]);
-      fclose(f);
-    }
-  }
-#endif
   if (mode == 0) {
     s->ev.push_back({e0, e1});
   } else {
@@ -486,15 +440,29 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       s->NT2 = per_simd - s->NT;
       if (s->NT2 < 1) s->NT2 = s->NT;
       s->n_pad = 16 * 3 * (s->NT + s->NT2);   // n <= 1056 -> NT <= 11
-      // more trait tiles than CUs: chained SNP segments even out the last round (3 rounds -> ~2.5 for 625 tiles)
-      if (s->ntile > s->ncu) {
+      // two trait tiles per workgroup once that still gives every CU a workgroup (C3: 625 tiles -> 313 workgroups of 32
+      // traits): X operands shared by two MFMAs, one chain evaluation per 32 traits, half the per-phase overhead.
+      // q is then padded to a multiple of 32 (the extra tile is all padding: zero residual, masked sums).
+      s->TT = ((s->ntile + 1) / 2 >= s->ncu) ? 2 : 1;
+      if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 2 ? 2 : 1;
+      if (s->TT == 2) {
+        s->q_pad = (pr->q + 31) / 32 * 32;
+        s->ntile = s->q_pad / 16;
+        // waves 4-6 enter a phase when their SIMD partner is a third of the way through it: one wave's hand-off gap
+        // (counter poll, delta read, accumulator drain, S' store) is then covered by the other's MFMAs
+        s->stagger = (s->NT + 2) / 3;
+      }
+      if (const char *e = getenv("AQ_STAGGER")) s->stagger = atoi(e) >= 0 ? atoi(e) : 0;
+      // more workgroups than CUs: chained SNP segments even out the last round (3 rounds -> ~2.5 for 625 workgroups)
+      const int nwg = s->ntile / s->TT;
+      if (nwg > s->ncu) {
         double best = 1e30;
         for (int S = 2; S <= 16; S++) {   // rounds of workgroups per sweep, in units of whole-sweep rounds
-          long long wg = (long long)s->ntile * S;
+          long long wg = (long long)nwg * S;
           double cost = (double)((wg + s->ncu - 1) / s->ncu) / S * (1.0 + 0.002 * S);
           if (cost < best - 1e-12) { best = cost; s->chain = S; }
         }
-        if (best >= (double)((s->ntile + s->ncu - 1) / s->ncu)) s->chain = 0;   // no gain over whole tiles
+        if (best >= (double)((nwg + s->ncu - 1) / s->ncu)) s->chain = 0;   // no gain over whole tiles
       }
       if (const char *e = getenv("AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
       if (s->chain > s->nb) s->chain = s->nb;
@@ -524,6 +492,10 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   }
   int rc = aq_probe_dmode(&s->dmode);
   if (rc != AQ_OK) { delete s; return rc; }
+  if (s->use_la && s->dmode != 0) {   // the look-ahead kernel is written for gfx950's accumulator map (row = 4 reg + lane / 16)
+    delete s;
+    return aq_fail(AQ_ERR_UNSUPPORTED, "this device reports an f64 MFMA accumulator layout the look-ahead kernel is not written for");
+  }
 
   s->A2_inv = pr->A2_inv; s->m0 = pr->m0; s->nu = pr->nu; s->rho = pr->rho; s->t02 = pr->t02;
   s->t02_inv = 1.0 / pr->t02;

@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed,env", [(101, {}), (102, {"AQ_CHAIN": "3"}), (103, {"AQ_MIS_C": "2", "AQ_CHAIN": "0"})])
+@pytest.mark.parametrize("seed,env", [(101, {}), (102, {"AQ_CHAIN": "3"}), (103, {"AQ_MIS_C": "2", "AQ_CHAIN": "0"}),
+                                      (104, {"AQ_TT": "2"}), (105, {"AQ_TT": "2", "AQ_CHAIN": "4", "AQ_STAGGER": "1"})])
 def test_random_shapes_match_oracle(seed, env, monkeypatch):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_parity
