@@ -54,11 +54,17 @@ struct AqCoreArgs {
   int stagger;           // look-ahead kernel: matrix waves 4-6 start a phase when their SIMD partner has issued this many tiles (0 = off)
   int *done;             // chained segments: done[group] = number of that group's segments already finished
   int *errflag;          // set when a bounded wait on done[] expires (results invalid, reported to the host)
+  long long *dbg;        // -DAQ_DIAG_TIME builds only: per (workgroup, wave) cycles spent waiting / in total (tools/prof_roles.sh)
   const double *theta;   // look-ahead kernel (fused pre-pass): theta_vb [p_pad], zeta_vb [q_pad] of this sweep
   const double *zeta;
   double sqrt_c;         // annealing: the Mills ratios are taken at sqrt(c) (theta_j + zeta_k), R/update_vb.R:219-224
   int c_is_one;
 };
+
+// Look-ahead kernel: 16-sample residual tiles owned by the RECURRENCE wave (on top of the 3 (NT + NT2) of the six matrix
+// waves).  With two trait tiles per workgroup a phase is long enough for that wave to run its chain and then some matrix
+// work on SIMD 3, which otherwise issues no MFMA at all.  Shared by the kernel template and the host's geometry.
+constexpr int aq_la_nt3(int NT, int TT) { return (TT == 2 && NT >= 8) ? 3 : 0; }
 
 __device__ __forceinline__ aq_d4 aq_mfma(double a, double b, aq_d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);

@@ -87,6 +87,8 @@ __device__ __forceinline__ void aq_static_for(F &&f) {
 template <int NT, int NT2, bool SEG, int TT>
 __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
   constexpr int NWM = 6;                        // matrix waves: 0,1,2,4,5,6
+  constexpr int NT3 = aq_la_nt3(NT, TT);        // residual tiles of the recurrence wave (its matrix work follows its chain)
+  constexpr int NPS = NWM + (NT3 > 0 ? 1 : 0);  // partial S' slots
   constexpr int NTR = 16 * TT;                  // traits per workgroup
   constexpr int ENT = 256 * TT;                 // entries of one SNP block: [snp][trait]
   constexpr int NG = 4 / TT;                    // 16*TT-lane groups of the recurrence / helper wave
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   // entry (snp j, trait ht) of a block lives at j * NTR + ht in the LDS arrays; group hg owns the rows hg + NG r
   const int ht = lane & (NTR - 1), hg = lane / NTR;
 
-  __shared__ double Sp[2][NWM][ENT];   // partial S' of each matrix wave [snp][trait]
+  __shared__ double Sp[2][NPS][ENT];   // partial S' of each wave that owns residual tiles [snp][trait]
   __shared__ double LA[2][ENT];        // A = log(1-Phi) - log Phi
   __shared__ double Lm1[2][ENT];       // old m1 = gam*mu
   __shared__ double LB[2][ENT];        // slope b of Z
@@ -135,11 +137,12 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   __shared__ double LGx[2][256];       // X_b'X_{b-1}  [j][i]
   __shared__ double Lgam[2][ENT], Lmu[2][ENT], Ldel[2][ENT];
   __shared__ double Lred[4][ENT];      // running column sums per helper entry
-  __shared__ double Lrn[NWM * 4][NTR];
+  __shared__ double Lrn[NPS * 4][NTR];
   // Point-to-point progress counters instead of a workgroup barrier per phase: Fl[0..5] = number of SNP blocks whose
   // partial S' matrix wave m has written, Fl[6] = blocks the recurrence wave has finished, Fl[7] = blocks the helper
   // wave has staged, Fl[8..10] = phases that matrix wave 0..2 has carried past its stagger tile (its SIMD partner 4..6
-  // starts the phase then).  Each wave waits only for what it really reads, so the matrix waves -- the critical path --
+  // starts the phase then), Fl[11] = phases the recurrence wave's own matrix work has finished (init mode: the helper may
+  // then reuse a beta buffer).  Each wave waits only for what it really reads, so the matrix waves -- the critical path --
   // never stop at a barrier.  LDS operations of a wave execute in order and the LDS is one pipeline per CU, so
   // "data stores; s_waitcnt lgkmcnt(0); counter store" on one side and "counter load ... ; data loads" on the other are
   // ordered; the asm memory clobbers keep the compiler from moving accesses across them.
@@ -151,9 +154,20 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) Flv[idx] = val;
   };
+#ifdef AQ_DIAG_TIME
+  long long dg_wait = 0, dg_wait_b = 0;   // waits on the matrix / recurrence counters; on the helper's and the stagger counters
+  const long long dg_t0 = __builtin_readcyclecounter();
+#endif
   auto wait_ge = [&](int idx, int val) __attribute__((always_inline)) {
+#ifdef AQ_DIAG_TIME
+    const long long t_in = __builtin_readcyclecounter();
+#endif
     while (Flv[idx] < val) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
+#ifdef AQ_DIAG_TIME
+    if (idx >= 7) dg_wait_b += __builtin_readcyclecounter() - t_in;
+    else dg_wait += __builtin_readcyclecounter() - t_in;
+#endif
   };
   if (tid < 16) Fl[tid] = 0;
 
@@ -176,6 +190,191 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     }
   }
 
+  // One code path for both kinds of matrix wave and both modes.  Phase i = 0 .. nblk + 1 of a segment starting at block b0:
+  //     update with block b0 + i - 2 (i >= 2; its delta must be out: recurrence counter >= i - 1)
+  //     S' of block b0 + i          (i < nblk, sweep mode only)           then announce i + 1 on this wave's counter.
+  // Phases without an update (or without S') run the same instruction stream with a zero delta (or drop the accumulator):
+  // 4 of the nblk + 2 phases of a segment do some idle MFMAs, and in exchange the tile loop exists once, without a branch.
+  // ROLE 0: matrix waves 0-2 (NT tiles each), 1: matrix waves 4-6 (NT2 each), 2: the recurrence wave (NT3 tiles; `hook(i)` runs
+  // its chain for block b0 + i - 1 at the top of phase i -- that block's S' is complete when every matrix wave has announced
+  // phase i - 1, and its own share of it was stored by this very wave at the end of its previous phase).
+  constexpr int NTT = 3 * (NT + NT2) + NT3;
+  const int nblk_s = a.mode == 1 ? 0 : nblk;       // init mode: no S'
+  auto run = [&](auto ntc, auto rolec, auto hook) __attribute__((always_inline)) {
+    constexpr int NTC = decltype(ntc)::value;
+    constexpr int ROLE = decltype(rolec)::value;
+    constexpr bool HI = ROLE == 0;
+    constexpr int ST = (NTC + 2) / 3;              // stagger: the SIMD partner enters the phase after this many tiles
+    const int my_t0 = ROLE == 0 ? mw * NT : ROLE == 1 ? 3 * NT + (mw - 3) * NT2 : 3 * (NT + NT2);
+    const int slot = ROLE == 2 ? NWM : mw;         // partial S' slot; progress counter: Fl[mw], the recurrence wave's is Fl[11]
+    // residual tiles: Rr[tt][t][r] <-> sample 16*(my_t0+t) + 4 r + g, trait col of tile tile0 + tt   (f64 MFMA D layout
+    // row = 4 reg + (lane >> 4): the host refuses to run this kernel on a device that reports the other map)
+    aq_d4 Rr[TT][NTC];
+    aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
+      constexpr int tt = decltype(ttc)::value;
+      const double *Rg = a.R + (size_t)(tile0 + tt) * a.n_pad * 16 + (size_t)(16 * my_t0 + g) * 16 + col;
+      aq_static_for<NTC>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+#pragma unroll
+        for (int r = 0; r < 4; r++) Rr[tt][t][r] = Rg[(16 * t + 4 * r) * 16];
+      });
+    });
+    // X operand streams: [nb][NTT][2][64] x 16 B; this wave's tiles start at my_t0, lane address = block base + voff
+    const unsigned voff = (unsigned)((my_t0 * 128 + lane) * 16);
+    const char *XUb = (const char *)a.XU, *XAb = (const char *)a.XA;
+    constexpr long long BLK = (long long)NTT * 128 * 16;   // bytes per SNP block
+    aq_v2 p0, p1, q0, q1, c0, c1, d0, d1;   // XU tiles alternate between (p0,p1) and (q0,q1), XA tiles between (c0,c1) and (d0,d1)
+    // Tile step t: U(t) = 4 TT MFMAs chained on Rr[.][t]; S(t-1) = 4 TT chained on acc, whose B operand Rr[.][t-1] was
+    // finished a whole step earlier.  Loads, all issued at the START of a step: XU(t+1) (used one step later) and XA(t)
+    // (used by S(t), one and a half steps later); tile 0 of the NEXT phase at the end of the last step.  Queue of
+    // outstanding loads at the waits, oldest first, two loads each:
+    //   t=0: [XU0 XA0 | XU1]           wait XU0 = vmcnt(4)
+    //   t=1: [XA0 XU1 | XU2 XA1]       wait XU1 = vmcnt(4) (XA0 is older: done as well)
+    //   t>=2: [XU(t) XA(t-1) | XU(t+1) XA(t)]   wait XU(t) = vmcnt(6), then XA(t-1) = vmcnt(4)
+    //   last: [XU(t) XA(t-1) | XA(t)]  vmcnt(4), vmcnt(2) (two tiles only: [XA0 XU1 | XA1] vmcnt(2)); then +XU'0: [XA(t) XU'0]
+    //         vmcnt(2); then +XA'0.
+    AQ_LD2(p0, p1, voff, XUb + seg_b0 * BLK);
+    AQ_LD2(c0, c1, voff, XAb + seg_b0 * BLK);
+    for (int i = 0; i <= nblk + 1; i++) {
+      const bool do_u = i >= 2, do_s = i < nblk_s;
+      const double mflag = do_u ? -1.0 : 0.0;
+      const int bu = seg_b0 + (i >= 2 ? i - 2 : 0), bs = seg_b0 + (i < nblk ? i : nblk - 1);
+      const int nbu = seg_b0 + (i >= 1 ? (i - 1 < nblk ? i - 1 : nblk - 1) : 0), nbs = seg_b0 + (i + 1 < nblk ? i + 1 : nblk - 1);
+      hook(i);
+      if (do_u && (ROLE != 2 || a.mode == 1)) wait_ge(6, i - 1);   // (sweep mode: the recurrence wave wrote that delta itself)
+      if (ROLE == 1 && a.stagger) wait_ge(8 + (mw - 3), i + 1);
+      double nd[TT][4];
+      {
+        // (4 s + g) NTR + 16 tt + col.  The lane id is recomputed here and hidden from the optimiser: kept in a register
+        // across the phase it was spilled in earlier versions, and the reload's s_waitcnt vmcnt(0) drained the operand prefetch
+        unsigned zero = 0;
+        asm volatile("" : "+v"(zero));
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+        const double *dl = &Ldel[bu & 1][(ln >> 4) * NTR + (ln & 15)];
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++)
+#pragma unroll
+          for (int s = 0; s < 4; s++) nd[tt][s] = dl[4 * NTR * s + 16 * tt] * mflag;   // (Ldel starts zeroed: never NaN)
+      }
+      aq_d4 acc[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; tt++) acc[tt] = (aq_d4){0, 0, 0, 0};
+      const char *xu = XUb + __builtin_amdgcn_readfirstlane(bu) * BLK, *xa = XAb + __builtin_amdgcn_readfirstlane(bs) * BLK;
+      const char *nxu = XUb + __builtin_amdgcn_readfirstlane(nbu) * BLK, *nxa = XAb + __builtin_amdgcn_readfirstlane(nbs) * BLK;
+      auto U = [&](auto tc, aq_v2 u0, aq_v2 u1) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
+          constexpr int tt = decltype(ttc)::value;
+          aq_d4 Rt = Rr[tt][t];
+          Rt = aq_mfma(u0.x, nd[tt][0], Rt);
+          Rt = aq_mfma(u0.y, nd[tt][1], Rt);
+          Rt = aq_mfma(u1.x, nd[tt][2], Rt);
+          Rt = aq_mfma(u1.y, nd[tt][3], Rt);
+          Rr[tt][t] = Rt;
+        });
+      };
+      auto S = [&](auto tc, aq_v2 x0, aq_v2 x1) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
+          constexpr int tt = decltype(ttc)::value;
+          const aq_d4 Rp = Rr[tt][t];
+          acc[tt] = aq_mfma(x0.x, Rp[0], acc[tt]);
+          acc[tt] = aq_mfma(x0.y, Rp[1], acc[tt]);
+          acc[tt] = aq_mfma(x1.x, Rp[2], acc[tt]);
+          acc[tt] = aq_mfma(x1.y, Rp[3], acc[tt]);
+        });
+      };
+      if constexpr (NTC == 1) {
+        using C0 = std::integral_constant<int, 0>;
+        AQ_WAIT2(0, p0, p1);
+        AQ_WAIT2(0, c0, c1);
+        U(C0{}, p0, p1);
+        if (HI && a.stagger) signal(8 + mw, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        AQ_LD2(p0, p1, voff, nxu);
+        S(C0{}, c0, c1);
+        __builtin_amdgcn_sched_barrier(0);
+        AQ_LD2(c0, c1, voff, nxa);
+      } else {
+        aq_static_for<NTC>([&](auto tc) __attribute__((always_inline)) {
+          constexpr int t = decltype(tc)::value;
+          constexpr bool even = (t & 1) == 0, last = (t == NTC - 1);
+          using TP = std::integral_constant<int, (t > 0 ? t - 1 : 0)>;   // the tile S' runs behind on
+          if constexpr (!last) {
+            constexpr int kb = (t + 1 + 2) / 4, imm = (t + 1 - 4 * kb) * 2048;   // tile t+1 relative to base group kb
+            if constexpr (even) { AQ_LD2I(q0, q1, voff, xu + kb * 8192, imm); }
+            else { AQ_LD2I(p0, p1, voff, xu + kb * 8192, imm); }
+          }
+          if constexpr (t >= 1) {
+            constexpr int kc = (t + 2) / 4, immc = (t - 4 * kc) * 2048;          // tile t of the XA stream
+            if constexpr (even) { AQ_LD2I(c0, c1, voff, xa + kc * 8192, immc); }
+            else { AQ_LD2I(d0, d1, voff, xa + kc * 8192, immc); }
+          }
+          // U(t)
+          if constexpr (t == 0) AQ_WAIT2(4, p0, p1);
+          else if constexpr (last && t == 1) AQ_WAIT2(2, q0, q1);   // two tiles only: [XA0 XU1 | XA1]
+          else if constexpr (last) { if constexpr (even) AQ_WAIT2(4, p0, p1); else AQ_WAIT2(4, q0, q1); }
+          else if constexpr (t == 1) { AQ_WAIT2(4, q0, q1); AQ_WAIT2(4, c0, c1); }
+          else if constexpr (even) AQ_WAIT2(6, p0, p1);
+          else AQ_WAIT2(6, q0, q1);
+          if constexpr (even) U(tc, p0, p1); else U(tc, q0, q1);
+          __builtin_amdgcn_sched_barrier(0);
+          // S(t-1): XA(t-1) sits in (d0,d1) for even t, in (c0,c1) for odd t
+          if constexpr (t >= 1) {
+            if constexpr (last) { if constexpr (even) AQ_WAIT2(2, d0, d1); else AQ_WAIT2(2, c0, c1); }
+            else if constexpr (t >= 2) { if constexpr (even) AQ_WAIT2(4, d0, d1); else AQ_WAIT2(4, c0, c1); }
+            if constexpr (even) S(TP{}, d0, d1); else S(TP{}, c0, c1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (last) {
+            AQ_LD2(p0, p1, voff, nxu);       // tile 0 of the next phase; (p0,p1) is free: XU(t) sat there only for even t, and U(t) is issued
+            if constexpr (even) { AQ_WAIT2(2, c0, c1); S(tc, c0, c1); }
+            else { AQ_WAIT2(2, d0, d1); S(tc, d0, d1); }
+            __builtin_amdgcn_sched_barrier(0);
+            AQ_LD2(c0, c1, voff, nxa);       // (c0,c1) held XA(t) for even t: S(t) is issued
+          }
+          if constexpr (HI && t + 1 == ST) {
+            if (a.stagger) signal(8 + mw, i + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      if (do_s) {
+        const int ps = bs & 1;
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) Sp[ps][slot][(4 * r + g) * NTR + 16 * tt + col] = acc[tt][r];
+      }
+      signal(ROLE == 2 ? 11 : mw, i + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(c0), "+v"(c1), "+v"(q0), "+v"(q1), "+v"(d0), "+v"(d1));   // the dangling prefetch
+    // ---- write the residual back and ||R_k||^2 partials ----
+    // (lane id and base pointer are re-derived behind an optimisation barrier: otherwise the addresses computed for
+    // the loads at the top are kept alive -- i.e. spilled -- across the whole sweep)
+    unsigned zero2 = 0;
+    asm volatile("" : "+v"(zero2));
+    const int ln2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero2));
+    double *Rout = a.R;
+    asm volatile("" : "+s"(Rout));
+    aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
+      constexpr int tt = decltype(ttc)::value;
+      double *Rg = Rout + (size_t)(tile0 + tt) * a.n_pad * 16 + (size_t)(16 * my_t0 + (ln2 >> 4)) * 16 + (ln2 & 15);
+      double rn = 0.0;
+      aq_static_for<NTC>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const double v = Rr[tt][t][r];
+          Rg[(16 * t + 4 * r) * 16] = v;
+          rn += v * v;
+        }
+      });
+      Lrn[slot * 4 + (ln2 >> 4)][16 * tt + (ln2 & 15)] = rn;
+    });
+  };
+  const auto no_hook = [](int) {};
+
   __syncthreads();   // counters and the helper's LDS initialisation are visible to every role
   if (is_rec) {
     // =========================== recurrence wave ===========================================
@@ -184,7 +383,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const double rc_cinv2s = a.c * a.inv2s[ktrait];
       const double rc_cst = a.cst[ktrait];
       const double rc_K = rc_coef * rc_coef * rc_cinv2s;   // keeps mu off the dependency chain of the recursion
-      for (int b = seg_b0; b < seg_b1; b++) {
+      auto chain_block = [&](int b) __attribute__((always_inline)) {
         const int par = b & 1;
         {   // block b needs its six partial S' and its staged scalars
           const int need = b - seg_b0 + 1;
@@ -203,7 +402,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           const int j = hg + NG * r;
           double sv = Sp[par][0][j * NTR + ht];
 #pragma unroll
-          for (int ww = 1; ww < NWM; ww++) sv += Sp[par][ww][j * NTR + ht];
+          for (int ww = 1; ww < NPS; ww++) sv += Sp[par][ww][j * NTR + ht];
           Sown[r] = sv;
         }
         if (b > seg_b0) {
@@ -246,7 +445,16 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           m1o = m1o_n; cA = cA_n; dj = d_n;
         }
         signal(6, b - seg_b0 + 1);   // delta, gam, mu of block b are in LDS
+      };
+      if constexpr (NT3 > 0) {
+        // chain for block b0 + i - 1, then this wave's share of the matrix work of phase i
+        run(std::integral_constant<int, (NT3 > 0 ? NT3 : 1)>{}, std::integral_constant<int, 2>{},
+            [&](int i) __attribute__((always_inline)) { if (i >= 1 && i <= nblk) chain_block(seg_b0 + i - 1); });
+      } else {
+        for (int b = seg_b0; b < seg_b1; b++) chain_block(b);
       }
+    } else if constexpr (NT3 > 0) {
+      run(std::integral_constant<int, (NT3 > 0 ? NT3 : 1)>{}, std::integral_constant<int, 2>{}, no_hook);   // init mode: R -= X beta on its tiles
     }
     __syncthreads();   // matches the matrix waves' barrier before the final sums
   } else if (helper) {
@@ -293,7 +501,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         LA[par][e] = valid ? A : 0.0;
         LB[par][e] = valid ? imr1 - imr0 : 0.0;
         Laa[par][e] = valid ? u + imr0 : 0.0;
-        if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two entries in flight, not RPG of them
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four entries in flight, not RPG of them
       }
 #pragma unroll
       for (int r = 0; r < RPG; r++) Lm1[par][lane + 64 * r] = st_g[r] * st_m[r];
@@ -338,6 +546,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         if (k >= 2) {
 #pragma unroll
           for (int m = 0; m < NWM; m++) wait_ge(m, k + 1);
+          if (NT3 > 0) wait_ge(11, k + 1);
         }
 #pragma unroll
         for (int r = 0; r < RPG; r++) {
@@ -376,193 +585,22 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     __syncthreads();   // matches the matrix waves' barrier before the final sums
   } else {
     // =========================== matrix waves ==============================================
-    // One code path for both kinds of matrix wave and both modes.  Phase i = 0 .. nblk + 1 of a segment starting at block b0:
-    //     update with block b0 + i - 2 (i >= 2; its delta must be out: recurrence counter >= i - 1)
-    //     S' of block b0 + i          (i < nblk, sweep mode only)           then announce i + 1 on this wave's counter.
-    // Phases without an update (or without S') run the same instruction stream with a zero delta (or drop the accumulator):
-    // 4 of the nblk + 2 phases of a segment do some idle MFMAs, and in exchange the tile loop exists once, without a branch.
-    constexpr int NTT = 3 * (NT + NT2);
-    const bool hi = mw < 3;                          // owns NT tiles (else NT2)
-    const int nblk_s = a.mode == 1 ? 0 : nblk;       // init mode: no S'
-    auto run = [&](auto ntc, auto hic) __attribute__((always_inline)) {
-      constexpr int NTC = decltype(ntc)::value;
-      constexpr bool HI = decltype(hic)::value;
-      constexpr int ST = (NTC + 2) / 3;              // stagger: the SIMD partner enters the phase after this many tiles
-      const int my_t0 = HI ? mw * NT : 3 * NT + (mw - 3) * NT2;
-      // residual tiles: Rr[tt][t][r] <-> sample 16*(my_t0+t) + 4 r + g, trait col of tile tile0 + tt   (f64 MFMA D layout
-      // row = 4 reg + (lane >> 4): the host refuses to run this kernel on a device that reports the other map)
-      aq_d4 Rr[TT][NTC];
-      aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
-        constexpr int tt = decltype(ttc)::value;
-        const double *Rg = a.R + (size_t)(tile0 + tt) * a.n_pad * 16 + (size_t)(16 * my_t0 + g) * 16 + col;
-        aq_static_for<NTC>([&](auto tc) __attribute__((always_inline)) {
-          constexpr int t = decltype(tc)::value;
-#pragma unroll
-          for (int r = 0; r < 4; r++) Rr[tt][t][r] = Rg[(16 * t + 4 * r) * 16];
-        });
-      });
-      // X operand streams: [nb][NTT][2][64] x 16 B; this wave's tiles start at my_t0, lane address = block base + voff
-      const unsigned voff = (unsigned)((my_t0 * 128 + lane) * 16);
-      const char *XUb = (const char *)a.XU, *XAb = (const char *)a.XA;
-      constexpr long long BLK = (long long)NTT * 128 * 16;   // bytes per SNP block
-      aq_v2 p0, p1, q0, q1, c0, c1, d0, d1;   // XU tiles alternate between (p0,p1) and (q0,q1), XA tiles between (c0,c1) and (d0,d1)
-      // Tile step t: U(t) = 4 TT MFMAs chained on Rr[.][t]; S(t-1) = 4 TT chained on acc, whose B operand Rr[.][t-1] was
-      // finished a whole step earlier.  Loads, all issued at the START of a step: XU(t+1) (used one step later) and XA(t)
-      // (used by S(t), one and a half steps later); tile 0 of the NEXT phase at the end of the last step.  Queue of
-      // outstanding loads at the waits, oldest first, two loads each:
-      //   t=0: [XU0 XA0 | XU1]           wait XU0 = vmcnt(4)
-      //   t=1: [XA0 XU1 | XU2 XA1]       wait XU1 = vmcnt(4) (XA0 is older: done as well)
-      //   t>=2: [XU(t) XA(t-1) | XU(t+1) XA(t)]   wait XU(t) = vmcnt(6), then XA(t-1) = vmcnt(4)
-      //   last: [XU(t) XA(t-1) | XA(t)]  vmcnt(4), vmcnt(2) (two tiles only: [XA0 XU1 | XA1] vmcnt(2)); then +XU'0: [XA(t) XU'0]
-      //         vmcnt(2); then +XA'0.
-      AQ_LD2(p0, p1, voff, XUb + seg_b0 * BLK);
-      AQ_LD2(c0, c1, voff, XAb + seg_b0 * BLK);
-      for (int i = 0; i <= nblk + 1; i++) {
-        const bool do_u = i >= 2, do_s = i < nblk_s;
-        const double mflag = do_u ? -1.0 : 0.0;
-        const int bu = seg_b0 + (i >= 2 ? i - 2 : 0), bs = seg_b0 + (i < nblk ? i : nblk - 1);
-        const int nbu = seg_b0 + (i >= 1 ? (i - 1 < nblk ? i - 1 : nblk - 1) : 0), nbs = seg_b0 + (i + 1 < nblk ? i + 1 : nblk - 1);
-        if (do_u) wait_ge(6, i - 1);
-        if (!HI && a.stagger) wait_ge(8 + (mw - 3), i + 1);
-        double nd[TT][4];
-        {
-          // (4 s + g) NTR + 16 tt + col.  The lane id is recomputed here and hidden from the optimiser: kept in a register
-          // across the phase it was spilled in earlier versions, and the reload's s_waitcnt vmcnt(0) drained the operand prefetch
-          unsigned zero = 0;
-          asm volatile("" : "+v"(zero));
-          const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
-          const double *dl = &Ldel[bu & 1][(ln >> 4) * NTR + (ln & 15)];
-#pragma unroll
-          for (int tt = 0; tt < TT; tt++)
-#pragma unroll
-            for (int s = 0; s < 4; s++) nd[tt][s] = dl[4 * NTR * s + 16 * tt] * mflag;   // (Ldel starts zeroed: never NaN)
-        }
-        aq_d4 acc[TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; tt++) acc[tt] = (aq_d4){0, 0, 0, 0};
-        const char *xu = XUb + __builtin_amdgcn_readfirstlane(bu) * BLK, *xa = XAb + __builtin_amdgcn_readfirstlane(bs) * BLK;
-        const char *nxu = XUb + __builtin_amdgcn_readfirstlane(nbu) * BLK, *nxa = XAb + __builtin_amdgcn_readfirstlane(nbs) * BLK;
-        auto U = [&](auto tc, aq_v2 u0, aq_v2 u1) __attribute__((always_inline)) {
-          constexpr int t = decltype(tc)::value;
-          aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
-            constexpr int tt = decltype(ttc)::value;
-            aq_d4 Rt = Rr[tt][t];
-            Rt = aq_mfma(u0.x, nd[tt][0], Rt);
-            Rt = aq_mfma(u0.y, nd[tt][1], Rt);
-            Rt = aq_mfma(u1.x, nd[tt][2], Rt);
-            Rt = aq_mfma(u1.y, nd[tt][3], Rt);
-            Rr[tt][t] = Rt;
-          });
-        };
-        auto S = [&](auto tc, aq_v2 x0, aq_v2 x1) __attribute__((always_inline)) {
-          constexpr int t = decltype(tc)::value;
-          aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
-            constexpr int tt = decltype(ttc)::value;
-            const aq_d4 Rp = Rr[tt][t];
-            acc[tt] = aq_mfma(x0.x, Rp[0], acc[tt]);
-            acc[tt] = aq_mfma(x0.y, Rp[1], acc[tt]);
-            acc[tt] = aq_mfma(x1.x, Rp[2], acc[tt]);
-            acc[tt] = aq_mfma(x1.y, Rp[3], acc[tt]);
-          });
-        };
-        if constexpr (NTC == 1) {
-          using C0 = std::integral_constant<int, 0>;
-          AQ_WAIT2(0, p0, p1);
-          AQ_WAIT2(0, c0, c1);
-          U(C0{}, p0, p1);
-          if (HI && a.stagger) signal(8 + mw, i + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          AQ_LD2(p0, p1, voff, nxu);
-          S(C0{}, c0, c1);
-          __builtin_amdgcn_sched_barrier(0);
-          AQ_LD2(c0, c1, voff, nxa);
-        } else {
-          aq_static_for<NTC>([&](auto tc) __attribute__((always_inline)) {
-            constexpr int t = decltype(tc)::value;
-            constexpr bool even = (t & 1) == 0, last = (t == NTC - 1);
-            using TP = std::integral_constant<int, (t > 0 ? t - 1 : 0)>;   // the tile S' runs behind on
-            if constexpr (!last) {
-              constexpr int kb = (t + 1 + 2) / 4, imm = (t + 1 - 4 * kb) * 2048;   // tile t+1 relative to base group kb
-              if constexpr (even) { AQ_LD2I(q0, q1, voff, xu + kb * 8192, imm); }
-              else { AQ_LD2I(p0, p1, voff, xu + kb * 8192, imm); }
-            }
-            if constexpr (t >= 1) {
-              constexpr int kc = (t + 2) / 4, immc = (t - 4 * kc) * 2048;          // tile t of the XA stream
-              if constexpr (even) { AQ_LD2I(c0, c1, voff, xa + kc * 8192, immc); }
-              else { AQ_LD2I(d0, d1, voff, xa + kc * 8192, immc); }
-            }
-            // U(t)
-            if constexpr (t == 0) AQ_WAIT2(4, p0, p1);
-            else if constexpr (last && t == 1) AQ_WAIT2(2, q0, q1);   // two tiles only: [XA0 XU1 | XA1]
-            else if constexpr (last) { if constexpr (even) AQ_WAIT2(4, p0, p1); else AQ_WAIT2(4, q0, q1); }
-            else if constexpr (t == 1) { AQ_WAIT2(4, q0, q1); AQ_WAIT2(4, c0, c1); }
-            else if constexpr (even) AQ_WAIT2(6, p0, p1);
-            else AQ_WAIT2(6, q0, q1);
-            if constexpr (even) U(tc, p0, p1); else U(tc, q0, q1);
-            __builtin_amdgcn_sched_barrier(0);
-            // S(t-1): XA(t-1) sits in (d0,d1) for even t, in (c0,c1) for odd t
-            if constexpr (t >= 1) {
-              if constexpr (last) { if constexpr (even) AQ_WAIT2(2, d0, d1); else AQ_WAIT2(2, c0, c1); }
-              else if constexpr (t >= 2) { if constexpr (even) AQ_WAIT2(4, d0, d1); else AQ_WAIT2(4, c0, c1); }
-              if constexpr (even) S(TP{}, d0, d1); else S(TP{}, c0, c1);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (last) {
-              AQ_LD2(p0, p1, voff, nxu);       // tile 0 of the next phase; (p0,p1) is free: XU(t) sat there only for even t, and U(t) is issued
-              if constexpr (even) { AQ_WAIT2(2, c0, c1); S(tc, c0, c1); }
-              else { AQ_WAIT2(2, d0, d1); S(tc, d0, d1); }
-              __builtin_amdgcn_sched_barrier(0);
-              AQ_LD2(c0, c1, voff, nxa);       // (c0,c1) held XA(t) for even t: S(t) is issued
-            }
-            if constexpr (HI && t + 1 == ST) {
-              if (a.stagger) signal(8 + mw, i + 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        }
-        if (do_s) {
-          const int ps = bs & 1;
-#pragma unroll
-          for (int tt = 0; tt < TT; tt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) Sp[ps][mw][(4 * r + g) * NTR + 16 * tt + col] = acc[tt][r];
-        }
-        signal(mw, i + 1);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(c0), "+v"(c1), "+v"(q0), "+v"(q1), "+v"(d0), "+v"(d1));   // the dangling prefetch
-      // ---- write the residual back and ||R_k||^2 partials ----
-      // (lane id and base pointer are re-derived behind an optimisation barrier: otherwise the addresses computed for
-      // the loads at the top are kept alive -- i.e. spilled -- across the whole sweep)
-      unsigned zero2 = 0;
-      asm volatile("" : "+v"(zero2));
-      const int ln2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero2));
-      double *Rout = a.R;
-      asm volatile("" : "+s"(Rout));
-      aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
-        constexpr int tt = decltype(ttc)::value;
-        double *Rg = Rout + (size_t)(tile0 + tt) * a.n_pad * 16 + (size_t)(16 * my_t0 + (ln2 >> 4)) * 16 + (ln2 & 15);
-        double rn = 0.0;
-        aq_static_for<NTC>([&](auto tc) __attribute__((always_inline)) {
-          constexpr int t = decltype(tc)::value;
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const double v = Rr[tt][t][r];
-            Rg[(16 * t + 4 * r) * 16] = v;
-            rn += v * v;
-          }
-        });
-        Lrn[mw * 4 + (ln2 >> 4)][16 * tt + (ln2 & 15)] = rn;
-      });
-    };
-    if (hi) run(std::integral_constant<int, NT>{}, std::true_type{});
-    else run(std::integral_constant<int, NT2>{}, std::false_type{});
+    if (mw < 3) run(std::integral_constant<int, NT>{}, std::integral_constant<int, 0>{}, no_hook);
+    else run(std::integral_constant<int, NT2>{}, std::integral_constant<int, 1>{}, no_hook);
     __syncthreads();
   }
+#ifdef AQ_DIAG_TIME
+  if (lane == 0 && a.dbg) {
+    a.dbg[((size_t)blockIdx.x * 8 + w) * 3] = dg_wait;
+    a.dbg[((size_t)blockIdx.x * 8 + w) * 3 + 1] = dg_wait_b;
+    a.dbg[((size_t)blockIdx.x * 8 + w) * 3 + 2] = __builtin_readcyclecounter() - dg_t0;
+  }
+#endif
   // ---- per-trait sums ----
   if (tid < NTR) {
     int k2 = tile0 * 16 + tid;
     double r2 = 0.0;
-    for (int s = 0; s < NWM * 4; s++) r2 += Lrn[s][tid];
+    for (int s = 0; s < NPS * 4; s++) r2 += Lrn[s][tid];
     double *sm = a.sums + (size_t)seg * 5 * a.q_pad;
     sm[(size_t)4 * a.q_pad + k2] = r2;
     for (int v = 0; v < 4; v++) {

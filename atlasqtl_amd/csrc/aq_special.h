@@ -77,23 +77,56 @@ AQ_HD double aq_recip_pos(double d) {
 #endif
 }
 
-// erfcx(z) = exp(z^2) erfc(z) for z >= 0: Chebyshev series in t = 4/(4+z) (coefficients from
-// tools/gen_erfcx_cheb.py, truncation 4e-18 relative), Clenshaw recurrence.  No exponential, no branch, no
-// underflow for any z -- which is why the pre-pass is built on it rather than on erfc.
+// erfcx(z) = exp(z^2) erfc(z) for z >= 0: the degree-24 Chebyshev fit in t = 4/(4+z) (coefficients from
+// tools/gen_erfcx_cheb.py, truncation 4e-18 relative), evaluated in the monomial basis of y = 2t - 1 as two interleaved
+// Horner chains in y^2 (even and odd powers): 26 fused operations with a dependent chain of 14, against 48 operations and
+// a chain of 48 for the Clenshaw recurrence, and slightly more accurate (the monomial coefficients decay like the
+// Chebyshev ones, sum |a_m| = 1.0003).  No exponential, no branch, no underflow for any z -- which is why the probit
+// terms are built on it rather than on erfc.
 AQ_HD double aq_erfcx_pos(double z) {
-  const double c[AQ_ERFCX_NCOEF] = {AQ_ERFCX_COEFS};
+  const double a[AQ_ERFCX_NCOEF] = {AQ_ERFCX_MONO};
   const double t = 4.0 * aq_recip_pos(4.0 + z);
-  const double x2 = 4.0 * t - 2.0;   // 2 (2t - 1)
-  double b1 = 0.0, b2 = 0.0;
+  const double y = fma(2.0, t, -1.0);
+  const double y2 = y * y;
+  double pe = a[24], po = a[23];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-  for (int j = AQ_ERFCX_NCOEF - 1; j >= 1; j--) {
-    double b0 = fma(x2, b1, c[j] - b2);
-    b2 = b1;
-    b1 = b0;
+  for (int j = 22; j >= 0; j -= 2) {
+    pe = fma(pe, y2, a[j]);
+    if (j >= 1) po = fma(po, y2, a[j - 1]);
   }
-  return t * fma(0.5 * x2, b1, c[0] - b2);
+  return t * fma(po, y, pe);
+}
+
+// log(x) for a positive NORMAL x (no zero / subnormal / inf / nan handling: the one caller guards its argument):
+// x = 2^e m, m in [sqrt(1/2), sqrt 2); log m = 2 atanh(s), s = (m - 1)/(m + 1), |s| <= 0.1716, odd series to s^21.
+// 30 operations instead of the ~60 of the library log with its special-case handling; error <= 1 ulp of the result or
+// 1e-17 absolute near x = 1.
+AQ_HD double aq_log_pos(double x) {
+  long long b;
+  __builtin_memcpy(&b, &x, 8);
+  int e = (int)((b >> 52) & 0x7ff) - 1023;
+  b = (b & 0x000fffffffffffffLL) | 0x3ff0000000000000LL;
+  double m;
+  __builtin_memcpy(&m, &b, 8);
+  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+  const double f = m - 1.0;
+  const double s = f * aq_recip_pos(2.0 + f);
+  const double z = s * s;
+  double p = 2.0 / 21.0;
+  p = fma(p, z, 2.0 / 19.0);
+  p = fma(p, z, 2.0 / 17.0);
+  p = fma(p, z, 2.0 / 15.0);
+  p = fma(p, z, 2.0 / 13.0);
+  p = fma(p, z, 2.0 / 11.0);
+  p = fma(p, z, 2.0 / 9.0);
+  p = fma(p, z, 2.0 / 7.0);
+  p = fma(p, z, 2.0 / 5.0);
+  p = fma(p, z, 2.0 / 3.0);
+  const double lm = fma(p * z, s, 2.0 * s);                 // log m
+  const double de = (double)e;
+  return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
 }
 
 // Everything the probit link needs at one point x, from ONE erfcx, ONE exp, ONE log and ONE log1p:
@@ -135,7 +168,9 @@ AQ_HD void aq_probit_A_imr(double x, double *A, double *imr1, double *imr0, doub
   const double inv_w = r * om, inv_om = r * w;
   const double rf = AQ_SQRT_2_OVER_PI * inv_w;
   const double rn = (AQ_INV_SQRT_2PI * E) * inv_om;
-  const double Apos = log(0.5 * w * inv_om) - hx2;     // log(e / (1 - e))
+  // 0.5 w / (1 - e) lies in (0, 1] and is normal for every |x| whose square is finite (w ~ 1/|x|); the clamp only keeps
+  // aq_log_pos inside its domain beyond that, where x^2/2 = inf decides the result anyway
+  const double Apos = aq_log_pos(fmax(0.5 * w * inv_om, 1e-300)) - hx2;     // log(e / (1 - e))
   double i1, i0;
   if (x > 0.0) { *A = Apos; i1 = rn; i0 = -rf; }
   else { *A = -Apos; i1 = rf; i0 = -rn; }

@@ -298,6 +298,15 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   } else if (s->use_la) {
     const unsigned nwg = (unsigned)(s->ntile / s->TT);
     a.done = s->done; a.errflag = s->errflag; a.stagger = s->stagger;
+    a.dbg = nullptr;
+    static long long *dbg_buf = nullptr;   // AQ_DIAG_DUMP=<file> with a -DAQ_DIAG_TIME build: per-role wait / total cycles of sweep 15
+    const char *dump = getenv("AQ_DIAG_DUMP");
+    const size_t dbg_n = (size_t)32 * nwg * 8 * 3;
+    if (dump && mode == 0) {
+      if (!dbg_buf) AQ_HIP(hipMalloc((void **)&dbg_buf, dbg_n * sizeof(long long)));
+      AQ_HIP(hipMemsetAsync(dbg_buf, 0, dbg_n * sizeof(long long), 0));
+      a.dbg = dbg_buf;
+    }
     const bool chained = (mode == 0 && s->chain > 1);
     a.nseg = chained ? s->chain : 1;
     if (chained) AQ_HIP(hipMemsetAsync(s->done, 0, (size_t)s->ntile * sizeof(int), 0));
@@ -307,6 +316,17 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
     if (chained)
       hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
+    if (a.dbg && s->it == 15) {
+      AQ_HIP(hipDeviceSynchronize());
+      std::vector<long long> h((size_t)grid * 24);
+      AQ_HIP(hipMemcpy(h.data(), a.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(dump, "w")) {
+        for (unsigned b = 0; b < grid; b++)
+          for (int w = 0; w < 8; w++)
+            fprintf(f, "%u %d %lld %lld %lld\n", b, w, h[((size_t)b * 8 + w) * 3], h[((size_t)b * 8 + w) * 3 + 1], h[((size_t)b * 8 + w) * 3 + 2]);
+        fclose(f);
+      }
+    }
   } else {
     return aq_fail(AQ_ERR_UNSUPPORTED, "no core kernel selected for this problem");
   }
@@ -430,16 +450,11 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       s->NE = per_lane <= 4 ? 4 : per_lane <= 8 ? 8 : per_lane <= 16 ? 16 : per_lane <= 32 ? 32 : 40;
     }
     if (!s->use_tw && !s->use_mis) {
-      // 6 matrix waves x NT residual tiles each (n padded to 96 NT samples) + the recurrence wave
+      // 6 matrix waves (NT tiles on waves 0-2, NT2 = NT or NT - 1 on waves 4-6: NT + NT2 per SIMD) + the recurrence wave,
+      // which owns aq_la_nt3(NT, TT) tiles of its own when two trait tiles share a workgroup
       s->use_la = true;
       const int ntiles = (pr->n + 15) / 16;
       s->NW = 6;
-      // per SIMD (waves w and w+4): NT + NT2 tiles, NT2 = NT or NT - 1  ->  n padded to 48 (NT + NT2) samples
-      const int per_simd = (ntiles + 2) / 3;
-      s->NT = (per_simd + 1) / 2;
-      s->NT2 = per_simd - s->NT;
-      if (s->NT2 < 1) s->NT2 = s->NT;
-      s->n_pad = 16 * 3 * (s->NT + s->NT2);   // n <= 1056 -> NT <= 11
       // two trait tiles per workgroup once that still gives every CU a workgroup (C3: 625 tiles -> 313 workgroups of 32
       // traits): X operands shared by two MFMAs, one chain evaluation per 32 traits, half the per-phase overhead.
       // q is then padded to a multiple of 32 (the extra tile is all padding: zero residual, masked sums).
@@ -448,9 +463,24 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       if (s->TT == 2) {
         s->q_pad = (pr->q + 31) / 32 * 32;
         s->ntile = s->q_pad / 16;
-        // waves 4-6 enter a phase when their SIMD partner is a third of the way through it: one wave's hand-off gap
-        // (counter poll, delta read, accumulator drain, S' store) is then covered by the other's MFMAs
-        s->stagger = (s->NT + 2) / 3;
+        // (waves 4-6 then enter a phase when their SIMD partner is a third of the way through it -- stagger, set below -- so
+        // that one wave's hand-off gap is covered by the other's MFMAs)
+      }
+      {
+        auto split = [&](int tiles_for_matrix) {
+          const int per_simd = (tiles_for_matrix + 2) / 3;
+          s->NT = (per_simd + 1) / 2;
+          s->NT2 = per_simd - s->NT;
+          if (s->NT2 < 1) s->NT2 = s->NT;
+        };
+        split(ntiles);
+        if (s->TT == 2 && ntiles > 3) {
+          const int NT_all = s->NT;
+          split(ntiles - 3);                                   // three tiles go to the recurrence wave ...
+          if (aq_la_nt3(s->NT, 2) != 3) { s->NT = NT_all; split(ntiles); }   // ... unless the kernel instance for this NT has none
+        }
+        s->n_pad = 16 * (3 * (s->NT + s->NT2) + aq_la_nt3(s->NT, s->TT));   // n <= 1056 -> NT <= 11
+        if (s->TT == 2) s->stagger = (s->NT + 2) / 3;
       }
       if (const char *e = getenv("AQ_STAGGER")) s->stagger = atoi(e) >= 0 ? atoi(e) : 0;
       // more workgroups than CUs: chained SNP segments even out the last round (3 rounds -> ~2.5 for 625 workgroups)
