@@ -64,7 +64,7 @@ struct AqCoreArgs {
 // Look-ahead kernel: 16-sample residual tiles owned by the RECURRENCE wave (on top of the 3 (NT + NT2) of the six matrix
 // waves).  With two trait tiles per workgroup a phase is long enough for that wave to run its chain and then some matrix
 // work on SIMD 3, which otherwise issues no MFMA at all.  Shared by the kernel template and the host's geometry.
-constexpr int aq_la_nt3(int NT, int TT) { return (TT == 2 && NT >= 8) ? 3 : 0; }
+constexpr int aq_la_nt3(int NT, int NT2, int TT) { return (TT == 2 && NT >= 8) ? (NT2 == NT ? 3 : 6) : 0; }
 
 __device__ __forceinline__ aq_d4 aq_mfma(double a, double b, aq_d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);

@@ -39,6 +39,23 @@
 
 typedef double aq_v2 __attribute__((ext_vector_type(2)));
 
+// Sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane: quad butterflies, then row rotations by
+// 4 and 8 (every quad holds its own sum by then).  Eight v_mov_b32 DPP + four v_add_f64 with register latency, where
+// __shfl_xor costs eight ds_bpermute_b32 round trips through the LDS pipeline.
+__device__ __forceinline__ double aq_row16_sum(double v) {
+  auto step = [&](auto ctrl) __attribute__((always_inline)) {
+    constexpr int C = decltype(ctrl)::value;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), C, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), C, 0xf, 0xf, false);
+    v += __hiloint2double(hi, lo);
+  };
+  step(std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  step(std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  step(std::integral_constant<int, 0x124>{});   // row_ror:4
+  step(std::integral_constant<int, 0x128>{});   // row_ror:8
+  return v;
+}
+
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The residual tiles live in
 // registers only while every index into them is a constant expression.
 template <int... Is, class F>
@@ -87,7 +104,7 @@ __device__ __forceinline__ void aq_static_for(F &&f) {
 template <int NT, int NT2, bool SEG, int TT>
 __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
   constexpr int NWM = 6;                        // matrix waves: 0,1,2,4,5,6
-  constexpr int NT3 = aq_la_nt3(NT, TT);        // residual tiles of the recurrence wave (its matrix work follows its chain)
+  constexpr int NT3 = aq_la_nt3(NT, NT2, TT);       // residual tiles of the recurrence wave (its matrix work follows its chain)
   constexpr int NPS = NWM + (NT3 > 0 ? 1 : 0);  // partial S' slots
   constexpr int NTR = 16 * TT;                  // traits per workgroup
   constexpr int ENT = 256 * TT;                 // entries of one SNP block: [snp][trait]
@@ -136,7 +153,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   __shared__ double LG[2][512];        // X_b'X_b as [16][32], upper 16 columns zero
   __shared__ double LGx[2][256];       // X_b'X_{b-1}  [j][i]
   __shared__ double Lgam[2][ENT], Lmu[2][ENT], Ldel[2][ENT];
-  __shared__ double Lred[4][ENT];      // running column sums per helper entry
+  __shared__ double Lred[4][64];       // the helper lanes' column sums [row group][trait], added up per trait at the end
   __shared__ double Lrn[NPS * 4][NTR];
   // Point-to-point progress counters instead of a workgroup barrier per phase: Fl[0..5] = number of SNP blocks whose
   // partial S' matrix wave m has written, Fl[6] = blocks the recurrence wave has finished, Fl[7] = blocks the helper
@@ -179,7 +196,6 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #pragma unroll
     for (int r = 0; r < RPG; r++) {
       const int e = lane + 64 * r;
-      Lred[0][e] = Lred[1][e] = Lred[2][e] = Lred[3][e] = 0.0;
       Ldel[0][e] = Ldel[1][e] = 0.0;   // read (times zero) by the matrix waves' first two phases
     }
 #pragma unroll
@@ -485,6 +501,8 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         st_G[r] = a.G[(size_t)b * 256 + lane + 64 * r];
         st_Gx[r] = a.Gx[(size_t)b * 256 + lane + 64 * r];
       }
+      // (the annealing test sits OUTSIDE the entry loop: a branch per entry would fence the entries off from each other, and
+      // the dependent chains of one probit evaluation -- ~100 operations -- need the other entries to fill the pipeline)
 #pragma unroll
       for (int r = 0; r < RPG; r++) {
         const int j = 16 * b + hg + NG * r, e = lane + 64 * r;
@@ -501,7 +519,6 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         LA[par][e] = valid ? A : 0.0;
         LB[par][e] = valid ? imr1 - imr0 : 0.0;
         Laa[par][e] = valid ? u + imr0 : 0.0;
-        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four entries in flight, not RPG of them
       }
 #pragma unroll
       for (int r = 0; r < RPG; r++) Lm1[par][lane + 64 * r] = st_g[r] * st_m[r];
@@ -512,28 +529,27 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         LGx[par][e] = st_Gx[r];
       }
     };
+    // running column sums of this lane's entries (they all belong to trait ht): sum gam, sum m2, sum beta^2, sum Z
+    double cs0 = 0.0, cs1 = 0.0, cs2 = 0.0, cs3 = 0.0;
     auto finalize = [&](int b, int par) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < RPG; r++) {
         const int e = lane + 64 * r, hj = hg + NG * r;
-        double gm = Lgam[par][e], mu = Lmu[par][e];
+        const double gm = Lgam[par][e], mu = Lmu[par][e];
         const size_t off = tbase + (size_t)(16 * b + hj) * 16;
         a.gam[off] = gm;
         a.mu[off] = mu;
         const int j = 16 * b + hj;
         double gb = 0.0;
         if (kvalid && j < a.p) {
-          double be = gm * mu;
+          const double be = gm * mu;
           gb = Laa[par][e] + gm * LB[par][e];       // Z_jk = a + gam b: its row and column sums are all that is needed
-          Lred[0][e] += gm;
-          Lred[1][e] += (mu * mu + sig2b_k) * gm;   // update_m2_beta_, R/update_vb.R:19-31
-          Lred[2][e] += be * be;
-          Lred[3][e] += gb;
+          cs0 += gm;
+          cs1 += (mu * mu + sig2b_k) * gm;          // update_m2_beta_, R/update_vb.R:19-31
+          cs2 += be * be;
+          cs3 += gb;
         }
-        gb += __shfl_xor(gb, 8, 64);
-        gb += __shfl_xor(gb, 4, 64);
-        gb += __shfl_xor(gb, 2, 64);
-        gb += __shfl_xor(gb, 1, 64);
+        gb = aq_row16_sum(gb);                      // over the 16 traits of the tile (one DPP row)
         if ((ht & 15) == 0) a.rowGB[(size_t)(tile0 + (ht >> 4)) * a.p_pad + j] = gb;
       }
     };
@@ -556,9 +572,9 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           double be = gm * mu;                                  // update_beta_vb_, R/update_vb.R:17
           Ldel[par][e] = be;
           if (kvalid && (16 * b + hj) < a.p) {
-            Lred[0][e] += gm;
-            Lred[1][e] += (mu * mu + sig2b_k) * gm;             // initial m2_beta, R/atlasqtl_global_local_core.R:113
-            Lred[2][e] += be * be;
+            cs0 += gm;
+            cs1 += (mu * mu + sig2b_k) * gm;                    // initial m2_beta, R/atlasqtl_global_local_core.R:113
+            cs2 += be * be;
           }
         }
         signal(6, k + 1);
@@ -582,6 +598,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       wait_ge(6, nblk);
       finalize(seg_b1 - 1, (seg_b1 - 1) & 1);
     }
+    Lred[0][lane] = cs0; Lred[1][lane] = cs1; Lred[2][lane] = cs2; Lred[3][lane] = cs3;   // [row group][trait]
     __syncthreads();   // matches the matrix waves' barrier before the final sums
   } else {
     // =========================== matrix waves ==============================================
@@ -605,7 +622,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     sm[(size_t)4 * a.q_pad + k2] = r2;
     for (int v = 0; v < 4; v++) {
       double acc2 = 0.0;
-      for (int jj = 0; jj < 16; jj++) acc2 += Lred[v][jj * NTR + tid];
+      for (int jj = 0; jj < NG; jj++) acc2 += Lred[v][jj * NTR + tid];
       sm[(size_t)v * a.q_pad + k2] = acc2;
     }
   }

@@ -467,19 +467,17 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         // that one wave's hand-off gap is covered by the other's MFMAs)
       }
       {
-        auto split = [&](int tiles_for_matrix) {
-          const int per_simd = (tiles_for_matrix + 2) / 3;
-          s->NT = (per_simd + 1) / 2;
-          s->NT2 = per_simd - s->NT;
-          if (s->NT2 < 1) s->NT2 = s->NT;
-        };
-        split(ntiles);
-        if (s->TT == 2 && ntiles > 3) {
-          const int NT_all = s->NT;
-          split(ntiles - 3);                                   // three tiles go to the recurrence wave ...
-          if (aq_la_nt3(s->NT, 2) != 3) { s->NT = NT_all; split(ntiles); }   // ... unless the kernel instance for this NT has none
-        }
-        s->n_pad = 16 * (3 * (s->NT + s->NT2) + aq_la_nt3(s->NT, s->TT));   // n <= 1056 -> NT <= 11
+        // smallest geometry that holds ntiles: NT in 1..11, NT2 in {NT, NT - 1}, plus the recurrence wave's aq_la_nt3 tiles;
+        // among equals the one with more tiles on the recurrence wave (AQ_NT3=0/3/6 pins its tile count for experiments)
+        const char *e3 = getenv("AQ_NT3");
+        int best_tiles = 1 << 30, best_nt3 = -1;
+        for (int NT = 1; NT <= 11; NT++)
+          for (int NT2 = NT; NT2 >= (NT > 1 ? NT - 1 : NT); NT2--) {
+            const int nt3 = aq_la_nt3(NT, NT2, s->TT), tiles = 3 * (NT + NT2) + nt3;
+            if (tiles < ntiles || (e3 && atoi(e3) != nt3 && s->TT == 2 && NT >= 8)) continue;
+            if (tiles < best_tiles || (tiles == best_tiles && nt3 > best_nt3)) { best_tiles = tiles; best_nt3 = nt3; s->NT = NT; s->NT2 = NT2; }
+          }
+        s->n_pad = 16 * best_tiles;                              // n <= 1056 always fits (11, 11)
         if (s->TT == 2) s->stagger = (s->NT + 2) / 3;
       }
       if (const char *e = getenv("AQ_STAGGER")) s->stagger = atoi(e) >= 0 ? atoi(e) : 0;
