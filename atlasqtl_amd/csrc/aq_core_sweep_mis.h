@@ -27,6 +27,7 @@
 #include "aq_special.h"
 #include "aq_core_sweep.h"
 #include "aq_vec_kernels.h"
+#include "aq_core_sweep_la.h"   // aq_static_for, aq_row16_sum
 
 #define AQ_MIS_MMAX 1024  // most missing samples of one trait the LDS index lists hold (16-bit indices, padded to 16)
 
@@ -102,21 +103,24 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
   unsigned short *Lidx = (unsigned short *)(Lcnt + 16);   // [16][Mmax]
 
   // ---- residual tiles and their mask bits into registers ----
+  // (f64 MFMA D layout row = 4 reg + (lane >> 4): the host refuses to run this kernel on a device that reports the other
+  // map; with it fixed, every tile address below is the wave's base plus a compile-time offset)
   aq_d4 Rr[NT];
   unsigned long long mb = 0;
   {
-    const double *Rg = a.R + (size_t)tile * a.n_pad * 16;
-    const double *Mg = a.mis + (size_t)tile * a.n_pad * 16;
-#pragma unroll
-    for (int t = 0; t < NT; t++)
+    const double *Rg = a.R + (size_t)tile * a.n_pad * 16 + (size_t)(16 * wt0 + g) * 16 + col;
+    const double *Mg = a.mis + (size_t)tile * a.n_pad * 16 + (size_t)(16 * wt0 + g) * 16 + col;
+    aq_static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        int s = 16 * (wt0 + t) + aq_drow(a.dmode, r, g);
-        Rr[t][r] = Rg[(size_t)s * 16 + col];
-        if (Mg[(size_t)s * 16 + col] != 0.0) mb |= 1ull << (4 * t + r);
+        Rr[t][r] = Rg[(16 * t + 4 * r) * 16];
+        if (Mg[(16 * t + 4 * r) * 16] != 0.0) mb |= 1ull << (4 * t + r);
       }
+    });
   }
-  auto remask = [&](int t) {
+  auto remask = [&](auto tc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value;
 #pragma unroll
     for (int r = 0; r < 4; r++) Rr[t][r] = ((mb >> (4 * t + r)) & 1ull) ? Rr[t][r] : 0.0;
   };
@@ -138,13 +142,13 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
   __syncthreads();
 
   // G_bb^(k) for the 16 traits of the tile -> LGk[buf]; waves 1,2,3,5,6,7 (never on the recurrence wave's SIMD)
-  auto compute_gk = [&](int bb, int buf) {
+  auto compute_gk = [&](int bb, int buf) __attribute__((always_inline)) {
     if (w == 0 || w == 4) return;
     const int slot = w < 4 ? w - 1 : w - 2;
     const double *xr = a.XR + (size_t)bb * a.NR * 16 + col;
     double gb[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) gb[r] = a.G[(size_t)bb * 256 + aq_drow(a.dmode, r, g) * 16 + col];
+    for (int r = 0; r < 4; r++) gb[r] = a.G[(size_t)bb * 256 + (4 * r + g) * 16 + col];
     double *dst = LGk + buf * (256 * 17);
     for (int k = slot; k < 16; k += 6) {
       aq_d4 acc = (aq_d4){0, 0, 0, 0};
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
         acc = aq_mfma(x3, x3, acc);
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) dst[(aq_drow(a.dmode, r, g) * 16 + col) * 17 + k] = gb[r] - acc[r];
+      for (int r = 0; r < 4; r++) dst[((4 * r + g) * 16 + col) * 17 + k] = gb[r] - acc[r];
     }
   };
 
@@ -187,30 +191,29 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
 #pragma unroll
       for (int s = 0; s < 4; s++) nd[s] = -Ldel[(4 * s + g) * 16 + col];
       const double2 *xu = XUw + (size_t)b * NTT * 128;
-#pragma unroll
-      for (int t = 0; t < NT; t++) {
+      aq_static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
         double2 u0 = xu[t * 128], u1 = xu[t * 128 + 64];
         Rr[t] = aq_mfma(u0.x, nd[0], Rr[t]);
         Rr[t] = aq_mfma(u0.y, nd[1], Rr[t]);
         Rr[t] = aq_mfma(u1.x, nd[2], Rr[t]);
         Rr[t] = aq_mfma(u1.y, nd[3], Rr[t]);
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
       __syncthreads();
     }
-#pragma unroll
-    for (int t = 0; t < NT; t++) remask(t);
+    aq_static_for<NT>([&](auto tc) __attribute__((always_inline)) { remask(tc); });
   } else {
     // ---------------- full sweep ----------------
     double st_A = 0, st_g = 0, st_m = 0, st_B = 0;
-    auto stage_load = [&](int b) {
+    auto stage_load = [&](int b) __attribute__((always_inline)) {
       size_t off = tbase + (size_t)(16 * b) * 16 + tid;
       st_A = a.Aarr[off];
       st_g = a.gam[off];
       st_m = a.mu[off];
       st_B = a.Barr[off];
     };
-    auto stage_commit = [&](int buf) {
+    auto stage_commit = [&](int buf) __attribute__((always_inline)) {
       const double xn = LGk[buf * (256 * 17) + (hj * 16 + hj) * 17 + hk];
       const double s2 = 1.0 / (a.c * (xn + sig2_inv) * tau_h);            // update_sig2_beta_vb_, R/update_vb.R:45
       const double ls2 = log(s2);
@@ -225,8 +228,8 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
     };
     // prologue: S of block 0, G^(k) of block 0, staged scalars of block 0
     aq_d4 acc = (aq_d4){0, 0, 0, 0};
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
+    aq_static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
       const double2 *xa0 = XAw + (size_t)seg_b0 * NTT * 128;
       double2 a0 = xa0[t * 128], a1 = xa0[t * 128 + 64];
       acc = aq_mfma(a0.x, Rr[t][0], acc);
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
       acc = aq_mfma(a1.x, Rr[t][2], acc);
       acc = aq_mfma(a1.y, Rr[t][3], acc);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     compute_gk(seg_b0, seg_b0 & 1);
     if (helper) stage_load(seg_b0);
     __syncthreads();
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
       const int buf = b & 1;
       if (helper && more) stage_load(b + 1);
 #pragma unroll
-      for (int i = 0; i < 4; i++) Sp[w * 256 + aq_drow(a.dmode, i, g) * 16 + col] = acc[i];
+      for (int i = 0; i < 4; i++) Sp[w * 256 + (4 * i + g) * 16 + col] = acc[i];
       aq_lds_barrier();
 
       if (w == 0) {
@@ -422,10 +425,7 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
           Lred[768 + tid] += gbv;
           Lred[1024 + tid] += gm * Lls2[tid];
         }
-        gbv += __shfl_xor(gbv, 8, 64);
-        gbv += __shfl_xor(gbv, 4, 64);
-        gbv += __shfl_xor(gbv, 2, 64);
-        gbv += __shfl_xor(gbv, 1, 64);
+        gbv = aq_row16_sum(gbv);
         if (hk == 0 && lead) a.rowGB[(size_t)tile * a.p_pad + j] = gbv;
       }
 
@@ -437,8 +437,8 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
       const double2 *xu = XUw + (size_t)b * NTT * 128;
       const double2 *xa = XAw + (size_t)(more ? b + 1 : b) * NTT * 128;
       double2 cu0 = xu[0], cu1 = xu[64], ca0 = xa[0], ca1 = xa[64];
-#pragma unroll
-      for (int t = 0; t < NT; t++) {
+      aq_static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
         double2 nu0, nu1, na0, na1;
         if (t + 1 < NT) {
           nu0 = xu[(t + 1) * 128]; nu1 = xu[(t + 1) * 128 + 64];
@@ -448,14 +448,15 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
         Rr[t] = aq_mfma(cu0.y, nd[1], Rr[t]);
         Rr[t] = aq_mfma(cu1.x, nd[2], Rr[t]);
         Rr[t] = aq_mfma(cu1.y, nd[3], Rr[t]);
-        remask(t);
+        remask(tc);
         acc = aq_mfma(ca0.x, Rr[t][0], acc);
         acc = aq_mfma(ca0.y, Rr[t][1], acc);
         acc = aq_mfma(ca1.x, Rr[t][2], acc);
         acc = aq_mfma(ca1.y, Rr[t][3], acc);
         if (t + 1 < NT) { cu0 = nu0; cu1 = nu1; ca0 = na0; ca1 = na1; }
+        asm volatile("" ::: "memory");   // the next tile's operand loads stay behind this one's (no hoisting of the whole stream)
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
       if (helper && more) stage_commit(buf ^ 1);
     }
   }
@@ -463,18 +464,25 @@ __global__ __launch_bounds__(512, 1) void aq_core_sweep_mis_kernel(const AqMisAr
   // ---- residual back, ||R_k||^2, column sums ----
   __syncthreads();
   {
-    double *Rg = a.R + (size_t)tile * a.n_pad * 16;
+    // (lane id and base pointer re-derived behind an optimisation barrier: otherwise the load addresses of the prologue are
+    // kept alive -- spilled -- across the whole sweep)
+    unsigned zero2 = 0;
+    asm volatile("" : "+v"(zero2));
+    const int ln2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero2));
+    double *Rout = a.R;
+    asm volatile("" : "+s"(Rout));
+    double *Rg = Rout + (size_t)tile * a.n_pad * 16 + (size_t)(16 * wt0 + (ln2 >> 4)) * 16 + (ln2 & 15);
     double rn = 0.0;
-#pragma unroll
-    for (int t = 0; t < NT; t++)
+    aq_static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        int s = 16 * (wt0 + t) + aq_drow(a.dmode, r, g);
-        double v = Rr[t][r];
-        Rg[(size_t)s * 16 + col] = v;
+        const double v = Rr[t][r];
+        Rg[(16 * t + 4 * r) * 16] = v;
         rn += v * v;
       }
-    Lrn[(w * 4 + g) * 16 + col] = rn;
+    });
+    Lrn[(w * 4 + (ln2 >> 4)) * 16 + (ln2 & 15)] = rn;
   }
   __syncthreads();
   if (tid < 16) {

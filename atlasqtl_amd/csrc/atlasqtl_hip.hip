@@ -520,9 +520,9 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   }
   int rc = aq_probe_dmode(&s->dmode);
   if (rc != AQ_OK) { delete s; return rc; }
-  if (s->use_la && s->dmode != 0) {   // the look-ahead kernel is written for gfx950's accumulator map (row = 4 reg + lane / 16)
+  if ((s->use_la || s->use_mis) && s->dmode != 0) {   // the MFMA sweep kernels are written for gfx950's accumulator map (row = 4 reg + lane / 16)
     delete s;
-    return aq_fail(AQ_ERR_UNSUPPORTED, "this device reports an f64 MFMA accumulator layout the look-ahead kernel is not written for");
+    return aq_fail(AQ_ERR_UNSUPPORTED, "this device reports an f64 MFMA accumulator layout the sweep kernels are not written for");
   }
 
   s->A2_inv = pr->A2_inv; s->m0 = pr->m0; s->nu = pr->nu; s->rho = pr->rho; s->t02 = pr->t02;
