@@ -35,7 +35,13 @@ class AqVbProblem(C.Structure):
         ("ext_reduce_main", C.c_void_p), ("ext_reduce_elbo", C.c_void_p), ("init_on_device", C.c_int32),
         ("init_generate", C.c_int32), ("trait_offset", C.c_int32), ("init_seed", C.c_uint64),
         ("init_gam_mean", C.c_double), ("init_gam_sd", C.c_double),
+        ("xy_on_device", C.c_int32),
     ]
+
+
+class AqPrepInput(C.Structure):
+    _fields_ = [("n", C.c_int32), ("p", C.c_int32), ("q", C.c_int32), ("X", dp), ("X_i8", C.POINTER(C.c_int8)), ("Y", dp),
+                ("device", C.c_int32)]
 
 
 class AqVbStatus(C.Structure):
@@ -67,6 +73,12 @@ SYMBOLS = {
     "aq_vb_get_status": (C.c_int, [C.c_void_p, C.POINTER(AqVbStatus)]),
     "aq_vb_get_elbo_trace": (C.c_int32, [C.c_void_p, ip, dp, C.c_int32]),
     "aq_vb_get_result": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
+    "aq_prepare_data": (C.c_int, [C.POINTER(AqPrepInput), C.POINTER(C.c_void_p)]),
+    "aq_prep_info": (C.c_int, [C.c_void_p, ip, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), ip, dp, dp]),
+    "aq_prep_x_device": (C.c_void_p, [C.c_void_p]),
+    "aq_prep_y_device": (C.c_void_p, [C.c_void_p]),
+    "aq_prep_get": (C.c_int, [C.c_void_p, dp, dp]),
+    "aq_prep_destroy": (None, [C.c_void_p]),
     "aq_assign_bfdr": (C.c_int, [dp, dp, C.c_int64, C.c_int32]),
     "aq_hotspot_sizes": (C.c_int, [dp, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64), C.c_int32]),

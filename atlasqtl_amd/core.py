@@ -101,12 +101,16 @@ class VbRun:
     def __init__(self, Y, X, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval=True, debug=True,
                  device=0, q_total=None, process_group=None, trait_offset=0):
         L = lib()
+        prep = X if hasattr(X, "x_ptr") else None       # prepare.PreparedData: standardised X and centred Y already on the GPU
         Y = np.asfortranarray(Y, dtype=np.float64)
-        X = np.asfortranarray(X, dtype=np.float64)
+        if prep is None:
+            X = np.asfortranarray(X, dtype=np.float64)
         n, p = X.shape
         if Y.shape[0] != n:
             raise ValueError("X and Y must have the same number of samples.")
         q = Y.shape[1]
+        if prep is not None and prep.device != int(device):
+            raise ValueError("PreparedData lives on another device")
         self.n, self.p, self.q = n, p, q
         self.q_total = int(q if q_total is None else q_total)
         self.pg = process_group
@@ -141,7 +145,14 @@ class VbRun:
             return as_dp(a)
 
         keep += [X, Y]
-        pr.X, pr.Y = as_dp(X), as_dp(Y)
+        if prep is None:
+            pr.X, pr.Y = as_dp(X), as_dp(Y)
+        else:
+            pr.X = C.cast(prep.x_ptr, _lib.dp)
+            if Y is prep.Y or (Y.shape == prep.Y.shape and np.array_equal(Y, prep.Y, equal_nan=True)):
+                pr.Y, pr.xy_on_device = C.cast(prep.y_ptr, _lib.dp), 3     # the centred Y that is already on the GPU
+            else:
+                pr.Y, pr.xy_on_device = as_dp(Y), 1                        # another Y (e.g. one trait shard of it) from the host
         pr.A2_inv = float(list_hyper["A2_inv"]); pr.m0 = float(list_hyper["m0"])
         pr.nu = float(list_hyper["nu"]); pr.rho = float(list_hyper["rho"]); pr.t02 = float(list_hyper["t02"])
         pr.eta = vec(list_hyper["eta"], q, "eta"); pr.kappa = vec(list_hyper["kappa"], q, "kappa")

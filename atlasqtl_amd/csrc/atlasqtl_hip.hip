@@ -379,12 +379,23 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   if (pr->world_size < 1) return aq_fail(AQ_ERR_ARG, "world_size must be >= 1");
   AQ_TRY(aq_need_device(pr->device));
 
-  // X must be complete; Y may hold NaN
+  // X must be complete; Y may hold NaN.  With xy_on_device both are device pointers: X is trusted to be the standardised
+  // NaN-free matrix of aq_prepare_data, Y (n x q, small) is copied back once for the missingness bookkeeping below.
   size_t np = (size_t)pr->n * pr->p, nq = (size_t)pr->n * pr->q;
-  for (size_t i = 0; i < np; i++)
-    if (!(pr->X[i] == pr->X[i])) return aq_fail(AQ_ERR_ARG, "X must be a non-empty a numeric matrix, finite without missing value.");
+  std::vector<double> Yhost;
+  const double *Yh = pr->Y;
+  const bool x_dev = (pr->xy_on_device & 1) != 0, y_dev = (pr->xy_on_device & 2) != 0;
+  if (y_dev) {
+    Yhost.resize(nq);
+    AQ_HIP(hipMemcpy(Yhost.data(), pr->Y, nq * sizeof(double), hipMemcpyDeviceToHost));
+    Yh = Yhost.data();
+  }
+  if (!x_dev) {
+    for (size_t i = 0; i < np; i++)
+      if (!(pr->X[i] == pr->X[i])) return aq_fail(AQ_ERR_ARG, "X must be a non-empty a numeric matrix, finite without missing value.");
+  }
   bool has_missing = false;
-  for (size_t i = 0; i < nq && !has_missing; i++) has_missing = !(pr->Y[i] == pr->Y[i]);
+  for (size_t i = 0; i < nq && !has_missing; i++) has_missing = !(Yh[i] == Yh[i]);
   if (pr->n > 10240)
     return aq_fail(AQ_ERR_UNSUPPORTED, "n > 10240: a trait's residual no longer fits the registers of 4 waves (not implemented yet)");
 
@@ -410,7 +421,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     if (has_missing) {
       for (int k = 0; k < pr->q; k++) {
         int m = 0;
-        for (int i = 0; i < pr->n; i++) m += !(pr->Y[(size_t)i + (size_t)pr->n * k] == pr->Y[(size_t)i + (size_t)pr->n * k]);
+        for (int i = 0; i < pr->n; i++) m += !(Yh[(size_t)i + (size_t)pr->n * k] == Yh[(size_t)i + (size_t)pr->n * k]);
         if (m > max_missing) max_missing = m;
       }
     }
@@ -561,7 +572,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       int m = 0;
       int *dst = idx.data() + (size_t)k * s->Mmax;      // trait k = tile (k / 16), slot (k % 16): contiguous
       for (int i = 0; i < s->n; i++)
-        if (!(pr->Y[(size_t)i + (size_t)s->n * k] == pr->Y[(size_t)i + (size_t)s->n * k])) dst[m++] = i;
+        if (!(Yh[(size_t)i + (size_t)s->n * k] == Yh[(size_t)i + (size_t)s->n * k])) dst[m++] = i;
       cnt[k] = (m + 15) / 16 * 4;
     }
     AQ_HIPF(hipMemcpy(s->midx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -603,8 +614,13 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   // ---- uploads + layout conversion (staging buffers freed afterwards) ----
   {
     double *Xd = nullptr;
-    AQ_HIPF(hipMalloc((void **)&Xd, np * sizeof(double)));
-    AQ_HIPF(hipMemcpy(Xd, pr->X, np * sizeof(double), hipMemcpyHostToDevice));
+    const bool own_x = !x_dev || s->use_tw;   // the generic kernel keeps X: it needs a copy of its own
+    if (own_x) {
+      AQ_HIPF(hipMalloc((void **)&Xd, np * sizeof(double)));
+      AQ_HIPF(hipMemcpy(Xd, pr->X, np * sizeof(double), x_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    } else {
+      Xd = const_cast<double *>(pr->X);
+    }
     if (s->use_tw) {
       s->Xcm = Xd;   // the generic kernel reads X column-major as given
     } else {
@@ -616,20 +632,20 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         hipLaunchKernelGGL(aq_k_build_xr, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, Xd, s->XR, s->n, s->p, s->nb, s->NR);
       }
       AQ_HIPF(hipDeviceSynchronize());
-      AQ_HIPF(hipFree(Xd));
+      if (own_x) AQ_HIPF(hipFree(Xd));
     }
   }
   {
     size_t big = (pr->init_on_device || pr->init_generate) ? nq : std::max((size_t)pr->p * pr->q, nq);
     double *stage = nullptr;
     AQ_HIPF(hipMalloc((void **)&stage, big * sizeof(double)));
-    AQ_HIPF(hipMemcpy(stage, pr->Y, nq * sizeof(double), hipMemcpyHostToDevice));
+    AQ_HIPF(hipMemcpy(stage, pr->Y, nq * sizeof(double), y_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->n_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->R,
                        s->n, s->q, s->n_pad, 1);
     AQ_HIPF(hipDeviceSynchronize());
     if (s->use_tw || s->use_mis) {   // mis_pat <- ifelse(is.na(Y), 0, 1), R/atlasqtl_global_local_core.R:21
       std::vector<double> mk(nq);
-      for (size_t i = 0; i < nq; i++) mk[i] = (pr->Y[i] == pr->Y[i]) ? 1.0 : 0.0;
+      for (size_t i = 0; i < nq; i++) mk[i] = (Yh[i] == Yh[i]) ? 1.0 : 0.0;
       AQ_HIPF(hipMemcpy(stage, mk.data(), nq * sizeof(double), hipMemcpyHostToDevice));
       hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->n_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->mis,
                          s->n, s->q, s->n_pad, 0);
@@ -673,7 +689,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     std::vector<double> nobs(s->q_pad, 0.0);
     for (int k = 0; k < s->q; k++) {                          // colSums(mis_pat), R/update_vb.R:132
       double cnt = 0;
-      for (int i = 0; i < s->n; i++) cnt += (pr->Y[(size_t)i + (size_t)s->n * k] == pr->Y[(size_t)i + (size_t)s->n * k]) ? 1.0 : 0.0;
+      for (int i = 0; i < s->n; i++) cnt += (Yh[(size_t)i + (size_t)s->n * k] == Yh[(size_t)i + (size_t)s->n * k]) ? 1.0 : 0.0;
       nobs[k] = cnt;
     }
     AQ_HIPF(hipMemcpy(s->nobs, nobs.data(), nobs.size() * sizeof(double), hipMemcpyHostToDevice));

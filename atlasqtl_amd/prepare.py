@@ -3,14 +3,17 @@
 Follows R/prepare_atlasqtl.R:8-124 (``prepare_data_``, ``check_verbose_``,
 ``check_annealing_``) and R/utils.R:10-100, 276-343 (``check_*_``,
 ``rm_constant_``, ``rm_collinear_``).  Error messages keep the reference's
-wording so tests read like the reference's own.  This is O(n p) host work that
-runs once per call; it is not part of the accelerated sweep.
+wording so tests read like the reference's own.  The argument checks run on the host;
+the O(n p) work itself -- scale(X), the removal of constant and duplicated columns,
+the centring of Y -- runs on the GPU (aq_prepare_data) and X stays there.
 """
 from __future__ import annotations
 
 import os
 
 import numpy as np
+
+from . import _lib
 
 _EPS75 = np.finfo(np.float64).eps ** 0.75
 
@@ -103,54 +106,85 @@ def check_annealing_(anneal):                                 # R/prepare_atlasq
                             "demanding. Please decrease it.")
 
 
-def scale_columns(X):
-    """R's scale(X): centre, divide by the n-1 standard deviation.  Constant
-    columns become NaN (0/0) exactly as in R, which rm_constant_ then detects."""
-    X = np.asarray(X, dtype=np.float64)
-    n = X.shape[0]
-    mean = X.mean(axis=0)
-    mean = mean + (X - mean).mean(axis=0)          # second pass: R's colMeans accumulates in long double
-    # a constant column has mean == its value exactly in R (0/0 = NaN below); numpy's pairwise sum can be an ulp off
-    # for non-dyadic values (0.1, 1/3), which would leave a finite +-0.99 column behind
-    const = X.max(axis=0) == X.min(axis=0)
-    mean = np.where(const, X[0], mean)
-    Xc = X - mean
-    sd = np.sqrt((Xc ** 2).sum(axis=0) / (n - 1))
-    with np.errstate(invalid="ignore", divide="ignore"):
-        return Xc / sd
+class PreparedData:
+    """The standardised compact X (n x p) and the centred Y resident on the GPU (aq_prepare_data).  VbRun takes it in place
+    of the X array; `Y` is the host copy of the centred responses (n x q, small) that the hyper-parameter rules need."""
+
+    def __init__(self, handle, n, p, q, Y, device):
+        self.handle, self.n, self.p, self.q, self.Y, self.device = handle, n, p, q, Y, device
+        self.shape = (n, p)
+
+    @property
+    def x_ptr(self):
+        return _lib.lib().aq_prep_x_device(self.handle)
+
+    @property
+    def y_ptr(self):
+        return _lib.lib().aq_prep_y_device(self.handle)
+
+    def X_host(self):
+        out = np.empty((self.n, self.p), order="F")
+        _lib.check(_lib.lib().aq_prep_get(self.handle, _lib.as_dp(out), None), "aq_prep_get")
+        return out
+
+    def close(self):
+        if self.handle is not None:
+            _lib.lib().aq_prep_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-def rm_constant_(mat, names):                                 # R/utils.R:276-302
-    bool_cst = np.isnan(mat.sum(axis=0))
-    rmvd = [names[i] for i in np.where(bool_cst)[0]] if bool_cst.any() else None
-    return mat[:, ~bool_cst], bool_cst, rmvd
-
-
-def rm_collinear_(mat, names):                                # R/utils.R:304-343
-    """duplicated(mat, MARGIN = 2): flag every column identical to an earlier one."""
-    seen = {}
-    bool_coll = np.zeros(mat.shape[1], dtype=bool)
-    rmvd = {}
-    for j in range(mat.shape[1]):
-        key = mat[:, j].tobytes()
-        if key in seen:
-            bool_coll[j] = True
-            rmvd[names[j]] = names[seen[key]]   # removed name -> kept name
-        else:
-            seen[key] = j
-    return mat[:, ~bool_coll], bool_coll, (rmvd if rmvd else None)
+def prepare_on_device(Y, X, device=0):
+    """scale(X), constant / duplicate-column removal and the centring of Y on the GPU (R/prepare_atlasqtl.R:57-83).
+    X: float64 (n x p) or int8 dosages (1 byte per genotype: the fp64 matrix is then never formed on the host).
+    Returns (PreparedData, bool_cst_x [p], bool_coll_x [p, original numbering], dup_of [p])."""
+    import ctypes as C
+    Y = np.asfortranarray(Y, dtype=np.float64)
+    n, q = Y.shape
+    pin = _lib.AqPrepInput()
+    if np.asarray(X).dtype == np.int8:
+        Xa = np.asfortranarray(X)
+        pin.X, pin.X_i8 = None, Xa.ctypes.data_as(C.POINTER(C.c_int8))
+    else:
+        Xa = np.asfortranarray(X, dtype=np.float64)
+        pin.X, pin.X_i8 = _lib.as_dp(Xa), None
+    if Xa.shape[0] != n:
+        raise AtlasqtlError("X and Y must have the same number of samples.")
+    p = Xa.shape[1]
+    pin.n, pin.p, pin.q, pin.Y, pin.device = n, p, q, _lib.as_dp(Y), int(device)
+    h = C.c_void_p()
+    rc = _lib.lib().aq_prepare_data(C.byref(pin), C.byref(h))
+    if rc != 0:
+        msg = _lib.lib().aq_last_error().decode("utf-8", "replace")
+        if rc == 1:
+            raise AtlasqtlError(msg)                       # where the reference calls stop()
+        raise _lib.AtlasqtlHipError(f"aq_prepare_data: [{rc}] {msg}")
+    pk = C.c_int32(0)
+    cst = np.zeros(p, dtype=np.uint8); coll = np.zeros(p, dtype=np.uint8); dup = np.zeros(p, dtype=np.int32)
+    _lib.check(_lib.lib().aq_prep_info(h, C.byref(pk), cst.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                       coll.ctypes.data_as(C.POINTER(C.c_uint8)), _lib.as_ip(dup), None, None), "aq_prep_info")
+    Yc = np.empty((n, q), order="F")
+    _lib.check(_lib.lib().aq_prep_get(h, None, _lib.as_dp(Yc)), "aq_prep_get")
+    return PreparedData(h, n, int(pk.value), q, Yc, int(device)), cst.astype(bool), coll.astype(bool), dup
 
 
 def prepare_data_(Y, X, tol, maxit, user_seed, verbose, checkpoint_path, trace_path,
-                  names_x=None, names_y=None):
+                  names_x=None, names_y=None, device=0):
     """R/prepare_atlasqtl.R:8-87.  Returns dict(Y, X, bool_rmvd_x, initial_colnames_X,
-    rmvd_cst_x, rmvd_coll_x, names_x, names_y)."""
+    rmvd_cst_x, rmvd_coll_x, names_x, names_y); X is a PreparedData (the standardised matrix lives on the GPU), Y the
+    centred responses on the host.  X may be float64 or int8 dosages."""
     check_vector_(user_seed, "user_seed", size=1, null_ok=True)
     check_vector_(tol, "tol", size=1)
     check_positive_(tol, "tol", eps=np.finfo(np.float64).eps)
     check_vector_(maxit, "maxit", size=1)
     check_natural_(maxit, "maxit")
-    X = check_matrix_(X, "X")
+    if not (isinstance(X, np.ndarray) and X.dtype == np.int8 and X.ndim == 2 and X.size > 0):
+        X = check_matrix_(X, "X")
     if checkpoint_path is not None and not os.path.isdir(checkpoint_path):
         raise AtlasqtlError("The directory specified in checkpoint_path does not exist. Please make sure to "
                             "provide a valid path.")
@@ -173,15 +207,12 @@ def prepare_data_(Y, X, tol, maxit, user_seed, verbose, checkpoint_path, trace_p
     if names_y is None:
         names_y = [f"Resp_{k + 1}" for k in range(q)]
 
-    Xs = scale_columns(X)
-    Xs, bool_cst_x, rmvd_cst_x = rm_constant_(Xs, names_x)
+    # scale(X), rm_constant_, rm_collinear_, centring of Y: on the device (aq_prepare.hip); X stays there
+    prep, bool_cst_x, bool_coll_full, dup_of = prepare_on_device(Y, X, device)
+    rmvd_cst_x = [names_x[j] for j in np.where(bool_cst_x)[0]] if bool_cst_x.any() else None
     names_after_cst = [nm for nm, b in zip(names_x, bool_cst_x) if not b]
-    Xs, bool_coll_x, rmvd_coll_x = rm_collinear_(Xs, names_after_cst)
-    bool_rmvd_x = bool_cst_x.copy()
-    bool_rmvd_x[~bool_cst_x] = bool_coll_x
-    if Xs.shape[1] < 1:
-        raise AtlasqtlError("There must be at least 1 non-constant candidate predictor stored in X.")
-    Yc = Y - np.nanmean(Y, axis=0)                         # scale(Y, center = TRUE, scale = FALSE)
-    return dict(Y=Yc, X=Xs, bool_rmvd_x=bool_rmvd_x, initial_colnames_X=names_after_cst,
+    bool_rmvd_x = bool_cst_x | bool_coll_full
+    rmvd_coll_x = {names_x[j]: names_x[dup_of[j]] for j in np.where(bool_coll_full)[0]} or None   # removed name -> kept name
+    return dict(Y=prep.Y, X=prep, bool_rmvd_x=bool_rmvd_x, initial_colnames_X=names_after_cst,
                 rmvd_cst_x=rmvd_cst_x, rmvd_coll_x=rmvd_coll_x,
-                names_x=[nm for nm, b in zip(names_after_cst, bool_coll_x) if not b], names_y=list(names_y))
+                names_x=[nm for nm, b in zip(names_x, bool_rmvd_x) if not b], names_y=list(names_y))

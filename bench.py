@@ -43,27 +43,39 @@ PMC_TRAFFIC_C3_BYTES = 4.11e10
 
 def build_problem(n, p, q_total, k0, k1, device, seed=123):
     """Synthetic hotspot-QTL data (shape of R/atlasqtl.R:125-157), identical for every
-    rank count: X, the q-vectors and Y are generated in full from fixed seeds and sliced;
-    the p x q initial values are generated on the GPU per 16-trait tile from a seed that
-    depends only on the global tile index."""
+    rank count: the int8 genotypes, the q-vectors and Y are generated in full from fixed seeds and
+    sliced; X is standardised on the GPU from the dosages and returned as a PreparedData (it never
+    exists as fp64 on the host); the p x q initial values are generated on the GPU per 16-trait tile
+    from a seed that depends only on the global tile index."""
     import torch
     from atlasqtl_amd import hyper_init as H
-    from atlasqtl_amd.prepare import scale_columns
+    from atlasqtl_amd.prepare import prepare_on_device
 
     rng = np.random.default_rng(seed)
     maf = rng.uniform(0.05, 0.5, size=p)
-    X = rng.binomial(2, maf[None, :], size=(n, p)).astype(np.float64)
-    X = scale_columns(X)
-    bad = ~np.isfinite(X).all(axis=0)
-    if bad.any():                       # a constant column (very unlikely at n = 1000): make it a fresh SNP
-        X[:, bad] = scale_columns(rng.binomial(2, 0.3, size=(n, int(bad.sum()))).astype(np.float64) + 1e-9 *
-                                  rng.normal(size=(n, int(bad.sum()))))
+    # genotypes as int8 dosages (1 byte each); scale(X) and the constant / duplicate-column check run on the GPU
+    # (aq_prepare_data, SURVEY 8f N1) and the standardised fp64 matrix only ever exists there
+    G = np.asfortranarray(rng.binomial(2, maf[None, :], size=(n, p)).astype(np.int8))
+    for _ in range(4):
+        Xprep, cst, coll, _dup = prepare_on_device(np.arange(n, dtype=np.float64).reshape(n, 1), G, device)   # (Y is prepared below, per rank)
+        bad = cst | coll
+        if not bad.any():
+            break
+        Xprep.close()                   # a constant or duplicated column (very unlikely at n = 1000): make it a fresh SNP
+        G[:, bad] = rng.binomial(2, 0.3, size=(n, int(bad.sum()))).astype(np.int8)
+    else:
+        raise RuntimeError("could not draw a genotype matrix without constant / duplicated columns")
+
+    def std_cols(idx):                  # the few columns the simulated effects need, standardised on the host
+        c = G[:, idx].astype(np.float64)
+        c -= c.mean(axis=0)
+        return c / np.sqrt((c ** 2).sum(axis=0) / (n - 1))
     p_act, q_act = 40, max(16, q_total // 4)
     act_x = np.sort(rng.choice(p, size=p_act, replace=False))
     act_y = np.sort(rng.choice(q_total, size=q_act, replace=False))
     beta = np.where(rng.random((p_act, q_act)) < 0.2, rng.normal(size=(p_act, q_act)), 0.0) * 0.3
     Y = rng.normal(size=(n, q_total))
-    Y[:, act_y] += X[:, act_x] @ beta
+    Y[:, act_y] += std_cols(act_x) @ beta
     Y -= Y.mean(axis=0)
     p0 = (5.0, 25.0)
     lh = H.auto_set_hyper_(Y, p, p0)
@@ -101,7 +113,7 @@ def build_problem(n, p, q_total, k0, k1, device, seed=123):
         gam[lo - k0:hi - k0] = torch.special.ndtr(n0 + (1e-4 + t02) * z[0, lo - t0:hi - t0])   # R/set_hyper_init.R:385
         mu[lo - k0:hi - k0] = z[1, lo - t0:hi - t0]                                           # :387
     li_loc["gam_vb"], li_loc["mu_beta_vb"] = gam, mu
-    return np.asfortranarray(X), np.asfortranarray(Y[:, sl]), lh_loc, li_loc
+    return Xprep, np.asfortranarray(Y[:, sl]), lh_loc, li_loc
 
 
 def cpu_baseline(n, p, q_total, seed=7, budget_s=10.0):

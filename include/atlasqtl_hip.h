@@ -115,6 +115,8 @@ typedef struct aq_vb_problem {
   int32_t trait_offset;        /* global index of this process's first trait (0 on one GPU)              */
   uint64_t init_seed;
   double init_gam_mean, init_gam_sd;
+  int32_t xy_on_device;        /* bit 0: X is a DEVICE pointer on `device` (e.g. aq_prep_x_device of aq_prepare_data), taken as
+                                  standardised and NaN-free without a host pass; bit 1: Y is a DEVICE pointer (aq_prep_y_device) */
 } aq_vb_problem;
 
 /* Length (in doubles) of the main all-reduce payload for a problem with p predictors:
@@ -173,6 +175,36 @@ int32_t aq_vb_get_elbo_trace(aq_vb_handle h, int32_t *it_out, double *lb_out, in
 int aq_vb_get_result(aq_vb_handle h, double *beta_vb, double *gam_vb, double *mu_beta_vb, double *theta_vb,
                      double *zeta_vb, double *lam2_inv_vb, double *sig2_theta_vb, double *tau_vb,
                      double *sig2_beta_vb);
+
+/* ------------------------------------------------------------------------------------------
+ * Input construction on the device: the O(n p) part of
+ *     prepare_data_(Y, X, ...)                                      R/prepare_atlasqtl.R:8-87
+ * i.e. X <- scale(X) (:57), rm_constant_ (R/utils.R:276-302), rm_collinear_ = duplicated(mat, MARGIN = 2) (:304-343),
+ * Y <- scale(Y, center = TRUE, scale = FALSE) (:83) and the two missingness guards (:39-45, same messages).
+ * X is given as fp64 (n x p column-major) or as int8 dosages X_i8 (0 / 1 / 2 ..., 1 byte per genotype; used when X is NULL),
+ * so that the fp64 genotype matrix need never exist on the host.  The standardised compact matrix (n x p_kept) and the
+ * centred Y stay on the device; pass aq_prep_x_device / aq_prep_y_device to aq_vb_create with xy_on_device = 1 (the handle
+ * must outlive that call only).
+ *   aq_prep_info   p_kept; bool_cst[p] (constant columns); bool_coll[p] (later copies of an identical column, in the
+ *                  ORIGINAL numbering); dup_of[p] (original index of the kept column a removed copy equals, else -1);
+ *                  the column means and n-1 standard deviations used.  Any pointer may be NULL.
+ *   aq_prep_get    copies the standardised X (n x p_kept) and / or the centred Y (n x q) to the host.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct aq_prep *aq_prep_handle;
+typedef struct aq_prep_input {
+  int32_t n, p, q;
+  const double *X;      /* n x p fp64, or NULL */
+  const int8_t *X_i8;   /* n x p int8 dosages, read when X is NULL */
+  const double *Y;      /* n x q, NaN = missing */
+  int32_t device;
+} aq_prep_input;
+int aq_prepare_data(const aq_prep_input *in, aq_prep_handle *out);
+int aq_prep_info(aq_prep_handle h, int32_t *p_kept, uint8_t *bool_cst, uint8_t *bool_coll, int32_t *dup_of, double *x_mean,
+                 double *x_sd);
+const double *aq_prep_x_device(aq_prep_handle h);
+const double *aq_prep_y_device(aq_prep_handle h);
+int aq_prep_get(aq_prep_handle h, double *X_out, double *Y_out);
+void aq_prep_destroy(aq_prep_handle h);
 
 /* ------------------------------------------------------------------------------------------
  * Post-processing of the posterior inclusion probabilities on the device.

@@ -38,7 +38,7 @@ def test_atlasqtl_matches_oracle_through_the_whole_wrapper():
                     add_collinear_back=False)
     assert vb.rmvd_cst_x == ["Cov_x_6"] and vb.rmvd_coll_x == {"Cov_x_10": "Cov_x_3"}
     dat = P.prepare_data_(Y, X, 0.1, 1000, None, 0, None, None)
-    ref = O.atlasqtl_global_local_core_(dat["Y"], dat["X"], Y.shape[1], (1, 2, 10), 1, 0.1, 1000, vb.list_hyper,
+    ref = O.atlasqtl_global_local_core_(dat["Y"], dat["X"].X_host(), Y.shape[1], (1, 2, 10), 1, 0.1, 1000, vb.list_hyper,
                                         vb.list_init, full_output=True)
     assert vb.it == ref["it"] and vb.converged == ref["converged"]
     assert abs(vb.lb_opt - ref["lb_opt"]) <= 1e-9 * abs(ref["lb_opt"])
@@ -63,7 +63,7 @@ def test_atlasqtl_options(anneal, thinned):
                     save_hyper=True, save_init=True)
     dat = P.prepare_data_(Y, X, 0.1, 1000, None, 0, None, None)
     tr = []
-    ref = O.atlasqtl_global_local_core_(dat["Y"], dat["X"], 9, anneal, 1, 0.1, 1000, vb.list_hyper, vb.list_init,
+    ref = O.atlasqtl_global_local_core_(dat["Y"], dat["X"].X_host(), 9, anneal, 1, 0.1, 1000, vb.list_hyper, vb.list_init,
                                         thinned_elbo_eval=thinned, trace=tr)
     assert vb.it == ref["it"] and vb.converged
     assert abs(vb.diff_lb - ref["diff_lb"]) < 1e-6

@@ -6,20 +6,22 @@ import atlasqtl_amd as A
 from atlasqtl_amd import hyper_init as H
 from atlasqtl_amd import prepare as P
 from atlasqtl_amd import synth
+from oracle import prepare_oracle as PO
 
 
 def test_scale_and_removals():
+    """The NumPy restatement of scale(X) / rm_constant_ / rm_collinear_ / centring (oracle/prepare_oracle.py: the checker of
+    the device-side preparation, tests/test_gpu_prepare.py)."""
     rng = np.random.default_rng(0)
     X = rng.binomial(2, 0.3, size=(50, 8)).astype(float)
     X[:, 3] = 1.0                      # constant  -> NaN after scale -> removed (R/utils.R:278)
     X[:, 6] = X[:, 1]                  # duplicate -> removed, later one dropped (R/utils.R:307)
     Y = rng.normal(size=(50, 4))
-    d = P.prepare_data_(Y, X, 0.1, 1000, None, 0, None, None)
-    assert d["X"].shape == (50, 6)
-    assert list(np.where(d["bool_rmvd_x"])[0]) == [3, 6]
-    assert d["rmvd_cst_x"] == ["Cov_x_4"] and d["rmvd_coll_x"] == {"Cov_x_7": "Cov_x_2"}
-    np.testing.assert_allclose((d["X"] ** 2).sum(0), 49.0)          # diag(X'X) = n - 1 (note N1)
-    np.testing.assert_allclose(d["Y"].mean(0), 0, atol=1e-14)
+    Xs, Yc, bool_cst, bool_coll = PO.prepare_xy(Y, X)
+    assert Xs.shape == (50, 6)
+    assert list(np.where(bool_cst)[0]) == [3] and list(np.where(bool_coll)[0]) == [5]      # column 6 of 8 = 5th non-constant
+    np.testing.assert_allclose((Xs ** 2).sum(0), 49.0)          # diag(X'X) = n - 1 (note N1)
+    np.testing.assert_allclose(Yc.mean(0), 0, atol=1e-14)
 
 
 @pytest.mark.parametrize("val", [0.1, 0.3, 1.0 / 3.0, 2.7])
@@ -30,11 +32,11 @@ def test_constant_non_dyadic_column_is_removed(val, n):
     rng = np.random.default_rng(n)
     X = rng.binomial(2, 0.3, size=(n, 5)).astype(float)
     X[:, 2] = val
-    Xs = P.scale_columns(X)
+    Xs = PO.scale_columns(X)
     assert np.isnan(Xs[:, 2]).all()
-    d = P.prepare_data_(rng.normal(size=(n, 3)), X, 0.1, 1000, None, 0, None, None)
-    assert list(np.where(d["bool_rmvd_x"])[0]) == [2]
-    np.testing.assert_allclose((d["X"] ** 2).sum(0), n - 1.0)
+    Xk, _, bool_cst, bool_coll = PO.prepare_xy(rng.normal(size=(n, 3)), X)
+    assert list(np.where(bool_cst)[0]) == [2] and not bool_coll.any()
+    np.testing.assert_allclose((Xk ** 2).sum(0), n - 1.0)
 
 
 def test_input_guards():
@@ -46,7 +48,7 @@ def test_input_guards():
     with pytest.raises(A.AtlasqtlError):
         P.prepare_data_(Y, Xn, 0.1, 10, None, 0, None, None)          # X must be NA-free (R/prepare_atlasqtl.R:19)
     Yn = Y.copy(); Yn[:, 1] = np.nan
-    with pytest.raises(A.AtlasqtlError, match="97.5% missing"):
+    with pytest.raises(A.AtlasqtlError, match="97.5% missing"):       # (checked on the host before anything goes to the GPU)
         P.prepare_data_(Yn, X, 0.1, 10, None, 0, None, None)
     with pytest.raises(A.AtlasqtlError, match="positive"):
         P.prepare_data_(Y, X, 0.0, 10, None, 0, None, None)
@@ -100,10 +102,12 @@ def test_auto_init_shapes_and_seed():
 
 def test_list_dimension_checks():
     d = synth.simulate(60, 20, 4, p_act=3, seed=1)
-    dat = P.prepare_data_(d["Y"], d["X"], 0.1, 10, None, 0, None, None)
-    p = dat["X"].shape[1]
-    bad = A.set_hyper(5, len(dat["bool_rmvd_x"]), 1.0, 1.0, -2.0, 0.01, 1.0, 0.1)
+    Xs, Yc, bool_cst, bool_coll = PO.prepare_xy(d["Y"], d["X"])
+    bool_rmvd_x = bool_cst.copy()
+    bool_rmvd_x[~bool_cst] = bool_coll
+    p = Xs.shape[1]
+    bad = A.set_hyper(5, len(bool_rmvd_x), 1.0, 1.0, -2.0, 0.01, 1.0, 0.1)
     with pytest.raises(A.AtlasqtlError, match=r"dimensions \(q\)"):
-        H.prepare_list_hyper_(bad, dat["Y"], p, (2, 4), dat["bool_rmvd_x"])
+        H.prepare_list_hyper_(bad, Yc, p, (2, 4), bool_rmvd_x)
     with pytest.raises(A.AtlasqtlError, match="must be an object of class"):
-        H.prepare_list_hyper_({"q_hyper": 4}, dat["Y"], p, (2, 4), dat["bool_rmvd_x"])
+        H.prepare_list_hyper_({"q_hyper": 4}, Yc, p, (2, 4), bool_rmvd_x)

@@ -2,7 +2,8 @@
 import numpy as np
 
 from atlasqtl_amd import hyper_init as H
-from atlasqtl_amd import prepare, synth
+from atlasqtl_amd import synth
+from oracle import prepare_oracle
 
 
 def make_problem(n, p, q, p_act=10, seed=123, init_seed=456, maf=0.2, p0=(5, 25), prob_assoc=0.2, na_frac=0.0,
@@ -10,11 +11,14 @@ def make_problem(n, p, q, p_act=10, seed=123, init_seed=456, maf=0.2, p0=(5, 25)
     """Synthetic data in the shape of the reference's example generator, pre-processed by the
     host mirror of prepare_data_, with automatic hyper-parameters and a seeded automatic init."""
     d = synth.simulate(n, p, q, p_act=p_act, q_act=q_act, seed=seed, maf=maf, prob_assoc=prob_assoc, na_frac=na_frac)
-    dat = prepare.prepare_data_(d["Y"], d["X"], 0.1, 1000, None, 0, None, None)
-    X, Y = dat["X"], dat["Y"]
+    # host arrays for both sides of a parity test: the NumPy restatement of prepare_data_ (the device-side preparation has
+    # its own tests against it, tests/test_gpu_prepare.py)
+    X, Y, bool_cst, bool_coll = prepare_oracle.prepare_xy(d["Y"], d["X"])
+    bool_rmvd_x = bool_cst.copy()
+    bool_rmvd_x[~bool_cst] = bool_coll
     pp = X.shape[1]
-    lh = H.prepare_list_hyper_(None, Y, pp, p0, dat["bool_rmvd_x"])
-    li = H.prepare_list_init_(None, Y, pp, p0, dat["bool_rmvd_x"], q, init_seed)
+    lh = H.prepare_list_hyper_(None, Y, pp, p0, bool_rmvd_x)
+    li = H.prepare_list_init_(None, Y, pp, p0, bool_rmvd_x, q, init_seed)
     return dict(X=X, Y=Y, list_hyper=lh, list_init=li, truth=d, n=n, p=pp, q=q)
 
 
