@@ -83,6 +83,10 @@ SYMBOLS = {
     "aq_hotspot_sizes": (C.c_int, [dp, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64), C.c_int32]),
     "aq_vb_hotspot_sizes": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "aq_vb_bfdr_begin": (C.c_int, [C.c_void_p]),
+    "aq_vb_bfdr_query": (C.c_int, [C.c_void_p, C.c_double, dp]),
+    "aq_vb_bfdr_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "aq_vb_bfdr_end": (None, [C.c_void_p]),
     "aq_vb_state_bytes": (C.c_int64, [C.c_void_p]),
     "aq_vb_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "aq_vb_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

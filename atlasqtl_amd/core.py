@@ -252,12 +252,103 @@ class VbRun:
         check(lib().aq_vb_set_sweep_budget(self.h, -1), "aq_vb_set_sweep_budget")
 
     def hotspot_sizes(self, thres=0.5, fdr_adjust=False):
-        """Hotspot sizes from the gam_vb resident on the device (no p x q copy to the host)."""
+        """Hotspot sizes from the gam_vb resident on the device (no p x q copy to the host): rowSums(gam_vb > thres), or
+        rowSums(assign_bFDR(gam_vb) < thres) with fdr_adjust (summary.atlasqtl / plot.atlasqtl,
+        R/summarise_output.R:98-105,177-182).  With a process group the counts cover the traits of ALL ranks; the FDR
+        ranking is global (assign_bFDR sorts all p q PPIs, R/summarise_output.R:207-223)."""
         rs = np.zeros(self.p, dtype=np.int64)
         tot = C.c_int64(0)
-        check(lib().aq_vb_hotspot_sizes(self.h, float(thres), int(bool(fdr_adjust)), rs.ctypes.data_as(C.POINTER(C.c_int64)),
-                                        C.byref(tot)), "aq_vb_hotspot_sizes")
-        return rs, int(tot.value)
+        if self.pg is None or not fdr_adjust:
+            check(lib().aq_vb_hotspot_sizes(self.h, float(thres), int(bool(fdr_adjust)), rs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            C.byref(tot)), "aq_vb_hotspot_sizes")
+            if self.pg is not None:
+                rs = self._sum_over_ranks(rs)
+            return rs, int(rs.sum()) if self.pg is not None else int(tot.value)
+        return self._hotspot_sizes_fdr_sharded(float(thres))
+
+    def _sum_over_ranks(self, a):
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if dist.get_backend(self.pg) != "gloo":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return t.cpu().numpy()
+
+    def _hotspot_sizes_fdr_sharded(self, thres):
+        """{FDR < thres} is a prefix of the global decreasing PPI order (the running mean of 1 - PPI never decreases along
+        it).  M(c) = mean of 1 - PPI over all entries >= c is the estimated FDR at the end of c's tie block; it grows as c
+        falls, so a bisection over the bit patterns of c in [0, max PPI] finds the smallest c* with M(c*) < thres: every
+        entry >= c* is in.  Of the next tie block down, the first entries (original order: lower ranks, then position) are
+        in for as long as the running mean stays below thres.  Every step all-reduces four numbers."""
+        import struct
+        import torch
+        import torch.distributed as dist
+        L = lib()
+        rank, world = dist.get_rank(self.pg), dist.get_world_size(self.pg)
+        bits = lambda x: struct.unpack("<q", struct.pack("<d", x))[0]
+        val = lambda b: struct.unpack("<d", struct.pack("<q", b))[0]
+        check(L.aq_vb_bfdr_begin(self.h), "aq_vb_bfdr_begin")
+        try:
+            def query(c):              # local five numbers, global sums of the first four
+                out = np.zeros(5)
+                check(L.aq_vb_bfdr_query(self.h, float(c), as_dp(out)), "aq_vb_bfdr_query")
+                return out, self._sum_over_ranks(out[:4].copy())
+
+            def below(c):              # M(c) < thres, with at least one entry >= c
+                _, g = query(c)
+                return g[0] > 0 and g[1] / g[0] < thres
+
+            vmax = self._max_over_ranks(query(2.0)[0][4])         # the largest PPI of all
+            rs = np.zeros(self.p, dtype=np.int64)
+            if not below(vmax):                                   # FDR of the very first entry >= thres: nothing qualifies
+                return rs, 0
+            if below(0.0):
+                c_star = 0.0
+            else:
+                lo, hi = bits(0.0), bits(vmax)                    # below(lo) false, below(hi) true
+                while hi - lo > 1:
+                    mid = (lo + hi) // 2
+                    lo, hi = (lo, mid) if below(val(mid)) else (mid, hi)
+                c_star = val(hi)
+            loc, g = query(c_star)
+            upto = int(loc[0])                                    # this rank's entries >= c*
+            n_star, s_star = float(g[0]), float(g[1])
+            tie_val = self._max_over_ranks(loc[4])                # next PPI value down, over all ranks (-1: none)
+            take, tie_first = 0, upto
+            if tie_val >= 0.0:
+                loc_t, g_t = query(tie_val)
+                t_loc, t_glob = int(loc_t[0]) - int(loc_t[2]), int(g_t[0] - g_t[2])
+                d = 1.0 - tie_val
+                step_ok = lambda i: (s_star + i * d) / (n_star + i) < thres      # running mean after i entries of the block
+                i = 0
+                if d > thres:                                     # (else the whole block would have qualified)
+                    i = int(max(0, min(t_glob, np.floor((thres * n_star - s_star) / (d - thres)))))
+                    while i > 0 and not step_ok(i):
+                        i -= 1
+                    while i < t_glob and step_ok(i + 1):
+                        i += 1
+                counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+                tl = torch.tensor([t_loc], dtype=torch.int64)
+                if dist.get_backend(self.pg) != "gloo":
+                    counts, tl = [c.cuda() for c in counts], tl.cuda()
+                dist.all_gather(counts, tl, group=self.pg)
+                before = sum(int(c.item()) for c in counts[:rank])                # ties of lower ranks come first
+                take = int(min(max(i - before, 0), t_loc))
+            check(L.aq_vb_bfdr_rows(self.h, upto, tie_first, take, rs.ctypes.data_as(C.POINTER(C.c_int64))), "aq_vb_bfdr_rows")
+            rs = self._sum_over_ranks(rs)
+            return rs, int(rs.sum())
+        finally:
+            L.aq_vb_bfdr_end(self.h)
+
+    def _max_over_ranks(self, v):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        if dist.get_backend(self.pg) != "gloo":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        return float(t.item())
 
     def get_state(self):
         """The complete loop state between two sweeps as one uint8 array (aq_vb_get_state): unlike the reference's

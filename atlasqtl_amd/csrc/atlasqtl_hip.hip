@@ -31,6 +31,11 @@ int aq_fail_ext(int code, const std::string &msg) { return aq_fail(code, msg); }
 // aq_postproc.hip (hipCUB sort / scan)
 int aq_bfdr_device(const double *d_ppi, double *d_fdr, int64_t len);
 int aq_row_count_device(const double *d_m, int64_t *d_rs, int p, int q, double thres, int lt);
+struct aq_shard_sorted;
+int aq_shard_sort(const double *d_ppi, int64_t len, aq_shard_sorted **out);
+int aq_shard_query(const aq_shard_sorted *s, double c, double out[5]);
+int aq_shard_rows(const aq_shard_sorted *s, int64_t upto, int64_t t0, int64_t take, int p, int64_t *rs_host);
+void aq_shard_free(aq_shard_sorted *s);
 #define AQ_HIP(call)                                                                                   \
   do {                                                                                                 \
     hipError_t e_ = (call);                                                                            \
@@ -179,6 +184,7 @@ struct aq_vb {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   double core_ms_acc = 0.0;
   int core_launches = 0;
+  aq_shard_sorted *bf = nullptr;   // this rank's sorted PPIs between aq_vb_bfdr_begin and aq_vb_bfdr_end
   bool failed = false;
   int fail_code = AQ_ERR_NUMERIC;   // why the handle failed (reported again by every later advance)
   std::string fail_msg;
@@ -202,6 +208,7 @@ static void aq_free_all(aq_vb *s) {
   }
   if (s->done) hipFree(s->done);
   if (s->errflag) hipFree(s->errflag);
+  if (s->bf) aq_shard_free(s->bf);
   delete s;
 }
 
@@ -1019,6 +1026,36 @@ extern "C" int aq_vb_hotspot_sizes(aq_vb_handle s, double thres, int32_t fdr_adj
   int rc = aq_hotspot_common(d_m, s->p, s->q, thres, fdr_adjust, rs_thres, nb_pairwise);
   hipFree(d_m);
   return rc;
+}
+
+// Bayesian FDR under trait sharding (aq_postproc.hip): the caller bisects over a PPI cutoff, all-reducing the five numbers
+// of aq_vb_bfdr_query over the ranks at every step (atlasqtl_amd/core.py::VbRun.hotspot_sizes).
+extern "C" int aq_vb_bfdr_begin(aq_vb_handle s) {
+  if (!s) return aq_fail(AQ_ERR_ARG, "NULL handle");
+  AQ_HIP(hipSetDevice(s->device));
+  if (s->bf) { aq_shard_free(s->bf); s->bf = nullptr; }
+  double *d_m = nullptr;
+  AQ_HIP(hipMalloc((void **)&d_m, (size_t)s->p * s->q * sizeof(double)));
+  hipLaunchKernelGGL(aq_k_colmajor_from_tile, dim3((s->p_pad + 63) / 64, s->ntile), dim3(256), 0, 0, s->gam, (const double *)nullptr,
+                     d_m, s->p, s->q, s->p_pad);
+  int rc = aq_shard_sort(d_m, (int64_t)s->p * s->q, &s->bf);
+  hipFree(d_m);
+  return rc;
+}
+extern "C" int aq_vb_bfdr_query(aq_vb_handle s, double c, double *out5) {
+  if (!s || !out5 || !s->bf) return aq_fail(AQ_ERR_ARG, "aq_vb_bfdr_query: call aq_vb_bfdr_begin first");
+  AQ_HIP(hipSetDevice(s->device));
+  return aq_shard_query(s->bf, c, out5);
+}
+extern "C" int aq_vb_bfdr_rows(aq_vb_handle s, int64_t upto, int64_t tie_first, int64_t take, int64_t *rs) {
+  if (!s || !rs || !s->bf) return aq_fail(AQ_ERR_ARG, "aq_vb_bfdr_rows: call aq_vb_bfdr_begin first");
+  if (upto < 0 || take < 0 || tie_first < 0 || upto > (int64_t)s->p * s->q || tie_first + take > (int64_t)s->p * s->q)
+    return aq_fail(AQ_ERR_ARG, "aq_vb_bfdr_rows: positions out of range");
+  AQ_HIP(hipSetDevice(s->device));
+  return aq_shard_rows(s->bf, upto, tie_first, take, s->p, rs);
+}
+extern "C" void aq_vb_bfdr_end(aq_vb_handle s) {
+  if (s && s->bf) { hipSetDevice(s->device); aq_shard_free(s->bf); s->bf = nullptr; }
 }
 
 // ------------------------------------------------------ checkpoint / resume ----

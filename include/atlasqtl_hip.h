@@ -210,7 +210,8 @@ void aq_prep_destroy(aq_prep_handle h);
  * Post-processing of the posterior inclusion probabilities on the device.
  *   aq_assign_bfdr       assign_bFDR, R/summarise_output.R:207-223: Bayesian FDR estimate of every entry of
  *                        mat_ppi (len = p*q, any layout: the function works on as.vector(mat_ppi)); ties keep their
- *                        original order as with R's order(decreasing = TRUE).  Host pointers.
+ *                        original order as with R's order(decreasing = TRUE).  Host pointers.  Any length that fits the
+ *                        device (64-bit positions from 2^32 entries on).
  *   aq_hotspot_sizes     rowSums(gam_vb > thres) / rowSums(assign_bFDR(gam_vb) < thres) and their total
  *                        (summary.atlasqtl / plot.atlasqtl, R/summarise_output.R:98-105,177-182); mat_ppi p x q
  *                        column-major on the host.
@@ -220,6 +221,18 @@ int aq_assign_bfdr(const double *mat_ppi, double *mat_fdr, int64_t len, int32_t 
 int aq_hotspot_sizes(const double *mat_ppi, int32_t p, int32_t q, double thres, int32_t fdr_adjust,
                      int64_t *rs_thres, int64_t *nb_pairwise, int32_t device);
 int aq_vb_hotspot_sizes(aq_vb_handle h, double thres, int32_t fdr_adjust, int64_t *rs_thres, int64_t *nb_pairwise);
+/* The same FDR thresholding when the traits are spread over several processes: assign_bFDR ranks ALL p q PPIs, so a
+ * shard cannot do it alone.  Each process sorts its shard once (aq_vb_bfdr_begin) and answers, for a PPI value c,
+ *   out5 = { #{ppi >= c}, sum(1 - ppi : ppi >= c), #{ppi > c}, sum(1 - ppi : ppi > c), largest ppi < c (or -1) }
+ * (aq_vb_bfdr_query).  Summed over the processes these give the running mean of 1 - PPI at the end of c's tie block -- the
+ * estimated FDR there, non-decreasing along the order -- so the caller bisects over c with one small all-reduce per
+ * step.  aq_vb_bfdr_rows then counts, per predictor, this shard's first `upto` entries of the order plus `take` entries of
+ * the tie block starting at sorted position tie_first (ties go in original order, R's order(decreasing = TRUE)).
+ * atlasqtl_amd/core.py::VbRun.hotspot_sizes drives it over torch.distributed. */
+int aq_vb_bfdr_begin(aq_vb_handle h);
+int aq_vb_bfdr_query(aq_vb_handle h, double c, double *out5);
+int aq_vb_bfdr_rows(aq_vb_handle h, int64_t upto, int64_t tie_first, int64_t take, int64_t *rs);
+void aq_vb_bfdr_end(aq_vb_handle h);
 
 /* ------------------------------------------------------------------------------------------
  * Checkpoint / resume.  The reference's checkpoint_ (R/utils.R:571-611, called at
