@@ -35,7 +35,7 @@ class AqVbProblem(C.Structure):
         ("ext_reduce_main", C.c_void_p), ("ext_reduce_elbo", C.c_void_p), ("init_on_device", C.c_int32),
         ("init_generate", C.c_int32), ("trait_offset", C.c_int32), ("init_seed", C.c_uint64),
         ("init_gam_mean", C.c_double), ("init_gam_sd", C.c_double),
-        ("xy_on_device", C.c_int32),
+        ("xy_on_device", C.c_int32), ("scheme", C.c_int32), ("df", C.c_int32),
     ]
 
 

@@ -99,7 +99,7 @@ class VbRun:
     library copies them, drives the aq_vb_advance protocol and fetches results."""
 
     def __init__(self, Y, X, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval=True, debug=True,
-                 device=0, q_total=None, process_group=None, trait_offset=0):
+                 device=0, q_total=None, process_group=None, trait_offset=0, scheme="global_local", df=1):
         L = lib()
         prep = X if hasattr(X, "x_ptr") else None       # prepare.PreparedData: standardised X and centred Y already on the GPU
         Y = np.asfortranarray(Y, dtype=np.float64)
@@ -181,7 +181,7 @@ class VbRun:
             pr.init_on_device = 0
         pr.sig02_inv_vb = float(list_init["sig02_inv_vb"])
         pr.sig2_beta_vb = vec(list_init["sig2_beta_vb"], q, "sig2_beta_vb")
-        pr.sig2_theta_vb = vec(list_init["sig2_theta_vb"], p, "sig2_theta_vb")
+        pr.sig2_theta_vb = vec(list_init["sig2_theta_vb"] if scheme != "global" else np.ones(p), p, "sig2_theta_vb")
         pr.tau_vb = vec(list_init["tau_vb"], q, "tau_vb")
         pr.theta_vb = vec(list_init["theta_vb"], p, "theta_vb")
         pr.zeta_vb = vec(list_init["zeta_vb"], q, "zeta_vb")
@@ -193,6 +193,8 @@ class VbRun:
         pr.debug = 1 if debug else 0
         pr.device = int(device); pr.world_size = int(self.world)
         pr.trait_offset = int(trait_offset)
+        pr.scheme = {"global_local": 0, "global": 1}[scheme]
+        pr.df = int(df)
         pr.ext_reduce_main = ext_main
         pr.ext_reduce_elbo = ext_elbo
         h = C.c_void_p()
@@ -399,6 +401,15 @@ class VbRun:
         return out
 
 
+def atlasqtl_global_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbose, list_hyper, list_init, checkpoint_path=None,
+                          full_output=False, thinned_elbo_eval=True, debug=False, batch="y", **kw):
+    """R/atlasqtl_global_core.R:8-366 on the GPU: the same sweep with ONE global scale for the hotspot propensities (no
+    horseshoe local scales; df is not used by that core).  list_init needs no sig2_theta_vb."""
+    return atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, 1, tol, maxit, verbose, list_hyper, list_init,
+                                       checkpoint_path=checkpoint_path, full_output=full_output,
+                                       thinned_elbo_eval=thinned_elbo_eval, debug=debug, batch=batch, scheme="global", **kw)
+
+
 def assign_bFDR(mat_ppi, device=0):
     """assign_bFDR of the reference (R/summarise_output.R:207-223) on the GPU: sort of all p q PPIs (hipCUB radix sort,
     ties in original order), running mean of 1 - PPI, scattered back."""
@@ -462,7 +473,7 @@ def _run_with_checkpoints(run, checkpoint_path, rate, maxit):
 def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbose, list_hyper, list_init,
                                 checkpoint_path=None, trace_path=None, full_output=False, thinned_elbo_eval=True,
                                 debug=False, batch="y", device=0, process_group=None, resume_from=None,
-                                checkpoint_rate=100, trait_offset=None):
+                                checkpoint_rate=100, trait_offset=None, scheme="global_local"):
     """R/atlasqtl_global_local_core.R:8-433 on the GPU.  Returns the reference's list
     (:426-428): beta_vb, gam_vb, theta_vb, zeta_vb, n, p, q, anneal, converged, it, maxit,
     tol, lb_opt, diff_lb (+ the variational parameters with full_output).
@@ -471,8 +482,8 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbo
     rank passes its own trait columns and shr_fac_inv = q of the whole problem.  trait_offset = global index of
     this rank's first trait: required with a process group when the p x q initial values are drawn on the device
     (the Philox counters are (SNP, global trait), so a sharded run reproduces the single-GPU draws)."""
-    if df != 1:
-        raise NotImplementedError("df != 1 is unreachable from atlasqtl() (df <- 1, R/atlasqtl.R:272)")
+    if df not in (1, 3):
+        raise NotImplementedError("df must be 1 or 3 (other odd df: compute_integral_hs_, R/utils.R:425-568, not built)")
     if batch != "y":
         raise ValueError("Batch scheme not defined. Exit.")            # :231
     if trace_path is not None:
@@ -482,7 +493,8 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbo
         raise ValueError("trait_offset is required with process_group when the initial values are drawn on the device: "
                          "without it every trait shard would start from the draws of traits 0..q_local-1")
     run = VbRun(Y, X, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval, debug, device=device,
-                q_total=int(shr_fac_inv), process_group=process_group, trait_offset=int(trait_offset or 0))
+                q_total=int(shr_fac_inv), process_group=process_group, trait_offset=int(trait_offset or 0), scheme=scheme,
+                df=df)
     try:
         if resume_from is not None:
             run.set_state(np.load(resume_from))

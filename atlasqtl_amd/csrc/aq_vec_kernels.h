@@ -17,7 +17,8 @@ struct AqScalars {
   double rho_xi_inv, xi_inv, nu_s0, rho_s0;       // S13, S15, S18
   double sum_theta;     // sum(theta_vb) after S17
   double sum_sig2_theta;
-  double elbo_C;        // e_theta_hs_ (replicated p-sum)
+  double sum_theta_sq;  // global-only core: sum (theta - m0)^2
+  double elbo_C;        // e_theta_hs_ / e_theta_ (replicated p-sum)
   double elbo;          // assembled ELBO
   unsigned long long lentz_mask[2];
   int lentz_iters;
@@ -470,7 +471,10 @@ __global__ void aq_k_pvec_finish(AqPvec v, AqScalars *sc, double c, double c_s, 
         Q = aq_lentz_finish(&s, L);                                                  // R/utils.R:419
       }
       v.Q[j] = Q;
-      lam = 1.0 / (Q * L) - 1.0;                                                     // :254
+      if (v.df == 3.0)                                                               // :258 (L is L / df here, :241)
+        lam = exp(-1.0986122886681098 /* log 3 */ - log(L) + log(1.0 - L * Q) - log(Q * (1.0 + L) - 1.0)) - 1.0 / 3.0;
+      else
+        lam = 1.0 / (Q * L) - 1.0;                                                   // :254
     }
     v.lam2_inv[j] = lam;
     double s02 = sc->sig02_inv * lam * v.shr;
@@ -524,6 +528,71 @@ __global__ void aq_k_scalars_post(AqPvec v, AqScalars *sc, double c_s, int nblk)
   }
 }
 
+// ---- the global-only core (atlasqtl_global_core_, R/atlasqtl_global_core.R:238-256): one scale for all hotspot propensities
+// sig2_theta (a scalar in the reference, stored per predictor here), theta, and the partial sums of theta and of
+// sig2_theta + theta^2 - 2 theta m0 + m0^2
+__global__ void aq_k_pvec_global(AqPvec v, AqScalars *sc, double c, int q_total) {
+  __shared__ double sh[256];
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double th_new = 0, t2 = 0, s2t = 0;
+  if (j < v.p) {
+    const double s02 = sc->sig02_inv * v.shr;
+    const double sig2_theta = 1.0 / (c * ((double)q_total + s02));                  // update_sig2_c0_vb_(q, 1 / sig02_inv / shr, c), :240
+    th_new = c * sig2_theta * (v.rsZ[j] + s02 * v.m0 - sc->sum_zeta_old);           // update_theta_vb_, :242
+    v.sig2_theta[j] = sig2_theta;
+    v.theta[j] = th_new;
+    v.lam2_inv[j] = 1.0;
+    t2 = sig2_theta + th_new * th_new - 2 * th_new * v.m0 + v.m0 * v.m0;            // :253
+    s2t = sig2_theta;
+  }
+  int nblk = gridDim.x;
+  double r;
+  sh[threadIdx.x] = th_new; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+  r = sh[0]; __syncthreads();
+  if (threadIdx.x == 0) v.part[blockIdx.x] = r;
+  sh[threadIdx.x] = t2; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+  r = sh[0]; __syncthreads();
+  if (threadIdx.x == 0) v.part[nblk + blockIdx.x] = r;
+  sh[threadIdx.x] = s2t; __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+  r = sh[0]; __syncthreads();
+  if (threadIdx.x == 0) v.part[2 * nblk + blockIdx.x] = r;
+}
+// nu_s0_vb, rho_s0_vb, sig02_inv_vb of the global-only core (nu_s0 = rho_s0 = 1/2, :96, :252-255)
+__global__ void aq_k_scalars_post_global(AqPvec v, AqScalars *sc, double c_s, int nblk) {
+  __shared__ double sh[1024];
+  double a = 0, b = 0, d = 0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+    a += v.part[i];
+    b += v.part[nblk + i];
+    d += v.part[2 * nblk + i];
+  }
+  a = aq_block_sum_1024(a, sh);
+  b = aq_block_sum_1024(b, sh);
+  d = aq_block_sum_1024(d, sh);
+  if (threadIdx.x == 0) {
+    double nu_s0 = c_s * (0.5 + (double)v.p / 2) - c_s + 1;        // :252
+    double rho_s0 = c_s * (0.5 + b / 2);                           // :253
+    sc->nu_s0 = nu_s0;
+    sc->rho_s0 = rho_s0;
+    sc->sig02_inv = nu_s0 / rho_s0;                                // :255
+    sc->sum_theta = a;
+    sc->sum_sig2_theta = d;
+    sc->sum_theta_sq = b - d;                                      // sum (theta - m0)^2, for e_theta_
+  }
+}
+// e_theta_ (R/elbo.R:74-81) with vec_sum_log_det_theta of R/atlasqtl_global_core.R:397 -> sc->elbo_C.  One thread.
+__global__ void aq_k_elbo_C_global(AqPvec v, AqScalars *sc) {
+  const double p = (double)v.p;
+  const double log_sig02_inv = aq_digamma(sc->nu_s0) - log(sc->rho_s0);
+  const double s2t = sc->sum_sig2_theta / p;
+  const double vsld = p * (log_sig02_inv + log(v.shr) + log(s2t));
+  const double sig02 = v.shr * sc->sig02_inv;
+  sc->elbo_C = (vsld - sig02 * sc->sum_theta_sq - p * sig02 * s2t + p) / 2;
+}
+
 // S19: zeta.  R/update_vb.R:99-110 (is_mat = FALSE).
 __global__ void aq_k_qpost(AqQvec v, const AqScalars *sc, double c, double sig2_zeta, double t02_inv) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -543,8 +612,12 @@ __global__ void aq_k_elbo_C(AqPvec v, AqScalars *sc) {
   double acc = 0.0;
   for (int j = threadIdx.x; j < v.p; j += blockDim.x) {
     double th = v.theta[j], s2 = v.sig2_theta[j], lam = v.lam2_inv[j], L = v.L[j];
-    acc += log_sig02p / 2 - sig02p * lam * (th * th + s2 - 2 * v.m0 * th + v.m0 * v.m0) / 2 + (log(s2) + 1) / 2
-           - 1.1447298858494001741434273513531 /* log(pi) */ + L * lam + log(v.Q[j]);
+    const double quad = log_sig02p / 2 - sig02p * lam * (th * th + s2 - 2 * v.m0 * th + v.m0 * v.m0) / 2 + (log(s2) + 1) / 2;
+    if (v.df == 3.0)   // R/elbo.R:95-105: log(6) + log(3)/2 - log(pi) - log_B + df L lam + ..., log_B = log(9) - log(Q (1 + L) - 1)
+      acc += quad + 1.791759469228055 + 0.5493061443340549 - 1.1447298858494001741434273513531
+             - (2.1972245773362196 - log(v.Q[j] * (1.0 + L) - 1.0)) + 3.0 * L * lam;
+    else
+      acc += quad - 1.1447298858494001741434273513531 /* log(pi) */ + L * lam + log(v.Q[j]);
   }
   acc = aq_block_sum_1024(acc, sh);
   if (threadIdx.x == 0) sc->elbo_C = acc;
@@ -590,6 +663,7 @@ __global__ void aq_k_elbo_q(AqQvec v, const AqScalars *sc, const double *Hpart, 
 struct AqElboConst {
   double nu_h, rho_h, A2_inv, t02_inv, vec_sum_log_det_zeta, sig2_zeta;
   double p, q_total;
+  int global_only;   // atlasqtl_global_core_: no local scales, sig02_inv ~ Gamma(1/2, 1/2) (R/atlasqtl_global_core.R:96,413-416)
 };
 
 __device__ __forceinline__ double aq_e_sig2_inv(double nu, double nu_vb, double log_s, double rho, double rho_vb,
@@ -617,5 +691,9 @@ __global__ void aq_k_elbo_final(AqScalars *sc, const double *ered, AqElboConst k
              + lgamma(sc->nu_s0);                                                                       // R/elbo.R:49-56
   double G = aq_e_sig2_inv(0.5, 1.0, log_xi_inv, k.A2_inv, sc->rho_xi_inv, sc->xi_inv);
   double H = aq_e_sig2_inv(k.nu_h, nu_e, log_sig2_inv_e, k.rho_h, rho_e, sig2_inv);
+  if (k.global_only) {   // elbo_F + elbo_G of R/atlasqtl_global_core.R:413-416 take the place of the horseshoe's F, G, H
+    F = 0.0;
+    G = aq_e_sig2_inv(0.5, sc->nu_s0, log_sig02_inv, 0.5, sc->rho_s0, sc->sig02_inv);
+  }
   sc->elbo = A + B + C + D + E + F + G + H;
 }

@@ -129,6 +129,7 @@ struct aq_vb {
   // hyper / control
   double A2_inv, m0, nu, rho, t02, t02_inv, shr;
   bool has_anneal;
+  int scheme = 0, df = 1;   // scheme 1 = global-only core (atlasqtl_global_core_); df of the horseshoe's half-t prior (1 or 3)
   double anneal[3];
   std::vector<double> ladder;
   double tol;
@@ -362,7 +363,7 @@ static AqPvec aq_pvec(aq_vb *s) {
   AqPvec v;
   v.theta = s->theta; v.sig2_theta = s->sig2_theta; v.L = s->L; v.lam2_inv = s->lam2_inv; v.Q = s->Q;
   v.rsZ = s->red; v.part = s->ppart; v.p = s->p; v.p_pad = s->p_pad; v.shr = s->shr; v.m0 = s->m0;
-  v.A2_inv = s->A2_inv; v.df = 1.0;
+  v.A2_inv = s->A2_inv; v.df = (double)s->df;
   return v;
 }
 
@@ -384,6 +385,12 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     if (pr->anneal[2] > 1000 || pr->anneal[2] < 2) return aq_fail(AQ_ERR_ARG, "Temperature grid size out of range.");
   }
   if (pr->world_size < 1) return aq_fail(AQ_ERR_ARG, "world_size must be >= 1");
+  if (pr->scheme != 0 && pr->scheme != 1) return aq_fail(AQ_ERR_ARG, "scheme must be 0 (global-local horseshoe) or 1 (global-only)");
+  const int df = pr->df == 0 ? 1 : pr->df;
+  if (pr->scheme == 0 && df != 1 && df != 3)
+    return aq_fail(AQ_ERR_UNSUPPORTED, "df must be 1 or 3 (other odd df need compute_integral_hs_, R/utils.R:425-568: not built)");
+  if (pr->scheme == 0 && df == 3 && pr->has_anneal)
+    return aq_fail(AQ_ERR_UNSUPPORTED, "df = 3 with annealing needs Kummer's 1F1 in update_annealed_lam2_inv_vb_ (R/update_vb.R:76-81): not built");
   AQ_TRY(aq_need_device(pr->device));
 
   // X must be complete; Y may hold NaN.  With xy_on_device both are device pointers: X is trusted to be the standardised
@@ -547,6 +554,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   s->t02_inv = 1.0 / pr->t02;
   s->shr = (double)pr->q_total;   // shr_fac_inv <- q, R/atlasqtl.R:218
   s->has_anneal = pr->has_anneal != 0;
+  s->scheme = pr->scheme; s->df = pr->scheme == 1 ? 1 : (pr->df == 0 ? 1 : pr->df);
   std::memcpy(s->anneal, pr->anneal, sizeof(s->anneal));
   s->tol = pr->tol; s->maxit = pr->maxit; s->thinned = pr->thinned_elbo_eval != 0; s->debug = pr->debug != 0;
   s->has_missing = has_missing || s->use_mis;   // the masked kernel produces the NA forms of the column sums (identical for complete Y)
@@ -776,10 +784,15 @@ static int aq_sweep_part_b(aq_vb *s) {
   AqPvec pv = aq_pvec(s);
   int ann = (s->annealing) ? 1 : 0;   // annealing & anneal_scale, :244
   hipLaunchKernelGGL(aq_k_take_reduced_scalars, dim3(1), dim3(1), 0, 0, s->sc, s->red + s->p_pad);
-  hipLaunchKernelGGL(aq_k_reset_lentz, dim3(1), dim3(1), 0, 0, s->sc);
-  hipLaunchKernelGGL(aq_k_pvec_L, dim3(s->pblk), dim3(256), 0, 0, pv, s->sc, s->c_s, ann);
-  hipLaunchKernelGGL(aq_k_pvec_finish, dim3(s->pblk), dim3(256), 0, 0, pv, s->sc, s->c, s->c_s, ann, s->q_total);
-  hipLaunchKernelGGL(aq_k_scalars_post, dim3(1), dim3(1024), 0, 0, pv, s->sc, s->c_s, s->pblk);
+  if (s->scheme == 1) {   // global-only core: R/atlasqtl_global_core.R:238-256
+    hipLaunchKernelGGL(aq_k_pvec_global, dim3(s->pblk), dim3(256), 0, 0, pv, s->sc, s->c, s->q_total);
+    hipLaunchKernelGGL(aq_k_scalars_post_global, dim3(1), dim3(1024), 0, 0, pv, s->sc, s->c_s, s->pblk);
+  } else {
+    hipLaunchKernelGGL(aq_k_reset_lentz, dim3(1), dim3(1), 0, 0, s->sc);
+    hipLaunchKernelGGL(aq_k_pvec_L, dim3(s->pblk), dim3(256), 0, 0, pv, s->sc, s->c_s, ann);
+    hipLaunchKernelGGL(aq_k_pvec_finish, dim3(s->pblk), dim3(256), 0, 0, pv, s->sc, s->c, s->c_s, ann, s->q_total);
+    hipLaunchKernelGGL(aq_k_scalars_post, dim3(1), dim3(1024), 0, 0, pv, s->sc, s->c_s, s->pblk);
+  }
   hipLaunchKernelGGL(aq_k_qpost, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, qv, s->sc, s->c, s->sig2_zeta, s->t02_inv);
   AQ_HIP(hipGetLastError());
   return AQ_OK;
@@ -791,7 +804,8 @@ static int aq_elbo_local(aq_vb *s) {
   // the pre-pass of the NEXT sweep (same refreshed theta + zeta, c = 1 here) also yields the p x q ELBO part
   AQ_TRY(aq_launch_prepass(s, s->c, 1));
   s->pre_done = !s->fused;
-  hipLaunchKernelGGL(aq_k_elbo_C, dim3(1), dim3(1024), 0, 0, pv, s->sc);
+  if (s->scheme == 1) hipLaunchKernelGGL(aq_k_elbo_C_global, dim3(1), dim3(1), 0, 0, pv, s->sc);
+  else hipLaunchKernelGGL(aq_k_elbo_C, dim3(1), dim3(1024), 0, 0, pv, s->sc);
   hipLaunchKernelGGL(aq_k_elbo_q, dim3(1), dim3(1024), 0, 0, qv, s->sc, s->Hpart, s->ntile * s->nHchunk, s->ered);
   AQ_HIP(hipGetLastError());
   return AQ_OK;
@@ -819,6 +833,7 @@ static int aq_elbo_finish(aq_vb *s, double *lb) {
   k.nu_h = s->nu; k.rho_h = s->rho; k.A2_inv = s->A2_inv; k.t02_inv = s->t02_inv;
   k.vec_sum_log_det_zeta = s->vec_sum_log_det_zeta; k.sig2_zeta = s->sig2_zeta;
   k.p = (double)s->p; k.q_total = (double)s->q_total;
+  k.global_only = s->scheme == 1 ? 1 : 0;
   hipLaunchKernelGGL(aq_k_elbo_final, dim3(1), dim3(1), 0, 0, s->sc, s->ered, k);
   AQ_HIP(hipGetLastError());
   AqScalars h;

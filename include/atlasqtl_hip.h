@@ -117,6 +117,13 @@ typedef struct aq_vb_problem {
   double init_gam_mean, init_gam_sd;
   int32_t xy_on_device;        /* bit 0: X is a DEVICE pointer on `device` (e.g. aq_prep_x_device of aq_prepare_data), taken as
                                   standardised and NaN-free without a host pass; bit 1: Y is a DEVICE pointer (aq_prep_y_device) */
+  /* SURVEY 8f N4 -- the other drivers over the same sweep:
+   *   scheme 0  atlasqtl_global_local_core_ (horseshoe, R/atlasqtl_global_local_core.R); df = 0 or 1: half-Cauchy local scales;
+   *             df = 3 (R/atlasqtl_global_local_core.R:258, R/elbo.R:95-105) without annealing
+   *   scheme 1  atlasqtl_global_core_ (one global scale, R/atlasqtl_global_core.R:117-320); sig2_theta_vb of list_init and
+   *             A2_inv are not used there                                                                               */
+  int32_t scheme;
+  int32_t df;
 } aq_vb_problem;
 
 /* Length (in doubles) of the main all-reduce payload for a problem with p predictors:

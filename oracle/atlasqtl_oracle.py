@@ -364,10 +364,22 @@ def e_tau_(eta, eta_vb, kappa, kappa_vb, log_tau_vb, tau_vb):                   
 
 
 def e_theta_hs_(lam2_inv_vb, L_vb, log_sig02_inv_vb, m0, theta_vb, Q_app, sig02_inv_vb, sig2_theta_vb, df=1):
-    assert df == 1                                                                    # :85-92
-    return float(np.sum(log_sig02_inv_vb / 2 - sig02_inv_vb * lam2_inv_vb
+    if df == 1:                                                                       # R/elbo.R:85-92
+        return float(np.sum(log_sig02_inv_vb / 2 - sig02_inv_vb * lam2_inv_vb
+                            * (theta_vb ** 2 + sig2_theta_vb - 2 * m0 * theta_vb + m0 ** 2) / 2
+                            + (np.log(sig2_theta_vb) + 1) / 2 - np.log(np.pi) + L_vb * lam2_inv_vb + np.log(Q_app)))
+    assert df == 3                                                                    # R/elbo.R:95-105 (L_vb is L / df)
+    log_B = np.log(9) - np.log(Q_app * (1 + L_vb) - 1)
+    return float(np.sum(np.log(6) + np.log(3) / 2 - np.log(np.pi) - log_B + df * L_vb * lam2_inv_vb
+                        + log_sig02_inv_vb / 2 - sig02_inv_vb * lam2_inv_vb
                         * (theta_vb ** 2 + sig2_theta_vb - 2 * m0 * theta_vb + m0 ** 2) / 2
-                        + (np.log(sig2_theta_vb) + 1) / 2 - np.log(np.pi) + L_vb * lam2_inv_vb + np.log(Q_app)))
+                        + (np.log(sig2_theta_vb) + 1) / 2))
+
+
+def e_theta_(m0, theta_vb, sig02_inv, sig2_theta_vb, vec_sum_log_det):               # R/elbo.R:74-81
+    p = len(theta_vb)
+    return float(np.sum(vec_sum_log_det - sig02_inv * np.dot(theta_vb - m0, theta_vb - m0)
+                        - p * sig02_inv * sig2_theta_vb + p) / 2)
 
 
 def e_y_(n, kappa, kappa_vb, log_tau_vb, m2_beta, sig2_inv_vb, tau_vb, mis_pat=None):   # :135-146
@@ -417,6 +429,32 @@ def elbo_global_local_(Y, A2_inv, beta_vb, df, eta, gam_vb, kappa, L_vb, lam2_in
     return tot
 
 
+def elbo_global_(Y, beta_vb, eta, gam_vb, kappa, log_1_pnorm, log_pnorm, m0, m2_beta, n0, nu, nu_s0, nu_s0_vb, rho,
+                 rho_s0, rho_s0_vb, shr_fac_inv, sig02_inv_vb, sig2_beta_vb, sig2_inv_vb, sig2_theta_vb, sig2_zeta_vb,
+                 t02_inv, tau_vb, theta_vb, vec_sum_log_det_zeta, zeta_vb, X_norm_sq, Y_norm_sq, cp_Y_X, cp_X_Xbeta,
+                 mis_pat):
+    """R/atlasqtl_global_core.R:372-421 (the global-only core; sig2_theta_vb is a scalar there)."""
+    n = Y.shape[0]
+    p = len(theta_vb)
+    eta_vb = update_eta_vb_(n, eta, gam_vb, mis_pat)                                   # :385
+    kappa_vb = update_kappa_vb_(n, Y_norm_sq, cp_Y_X, cp_X_Xbeta, kappa, beta_vb, m2_beta, sig2_inv_vb, X_norm_sq)
+    nu_vb = update_nu_vb_(nu, gam_vb.sum())                                            # :389
+    rho_vb = update_rho_vb_(rho, m2_beta, tau_vb)
+    log_tau_vb = update_log_tau_vb_(eta_vb, kappa_vb)
+    log_sig2_inv_vb = update_log_sig2_inv_vb_(nu_vb, rho_vb)
+    log_sig02_inv_vb = update_log_sig2_inv_vb_(nu_s0_vb, rho_s0_vb)                    # :395
+    vec_sum_log_det_theta = p * (log_sig02_inv_vb + np.log(shr_fac_inv) + np.log(sig2_theta_vb))   # :397
+    A = e_y_(n, kappa, kappa_vb, log_tau_vb, m2_beta, sig2_inv_vb, tau_vb, mis_pat)
+    B = e_beta_gamma_(gam_vb, log_1_pnorm, log_pnorm, log_sig2_inv_vb, log_tau_vb, zeta_vb, theta_vb, m2_beta,
+                      sig2_beta_vb, sig2_zeta_vb, np.full(p, float(sig2_theta_vb)), sig2_inv_vb, tau_vb)
+    C = e_theta_(m0, theta_vb, shr_fac_inv * sig02_inv_vb, float(sig2_theta_vb), vec_sum_log_det_theta)   # :406
+    D = e_zeta_(zeta_vb, n0, sig2_zeta_vb, t02_inv, vec_sum_log_det_zeta)
+    E = e_tau_(eta, eta_vb, kappa, kappa_vb, log_tau_vb, tau_vb)
+    F = e_sig2_inv_(nu, nu_vb, log_sig2_inv_vb, rho, rho_vb, sig2_inv_vb)
+    G = e_sig2_inv_(nu_s0, nu_s0_vb, log_sig02_inv_vb, rho_s0, rho_s0_vb, sig02_inv_vb)     # :415
+    return float(A + B + C + D + E + F + G)
+
+
 class ElboNotMonotone(RuntimeError):
     pass
 
@@ -424,10 +462,18 @@ class ElboNotMonotone(RuntimeError):
 # ----------------------------------------------------------------------------
 # the driver: R/atlasqtl_global_local_core.R:8-433
 # ----------------------------------------------------------------------------
+def atlasqtl_global_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_hyper, list_init, **kw):
+    """Restatement of the global-only core atlasqtl_global_core_ (R/atlasqtl_global_core.R:8-366): the same sweep with
+    one global scale for the hotspot propensities instead of the horseshoe's local ones (df is unused there)."""
+    return atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, 1, tol, maxit, list_hyper, list_init, scheme="global", **kw)
+
+
 def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_hyper, list_init,
                                 thinned_elbo_eval=True, debug=True, inner="c", trace=None,
-                                full_output=False):
-    """Restatement of atlasqtl_global_local_core_ (batch == "y").  Y may contain
+                                full_output=False, scheme="global_local"):
+    """Restatement of atlasqtl_global_local_core_ (batch == "y").  scheme = "global": the p-vector part and the ELBO of
+    atlasqtl_global_core_ (R/atlasqtl_global_core.R:236-256,372-421) instead; df in {1, 3} (df = 3 without annealing:
+    the annealed update of lam2_inv_vb needs Kummer's 1F1, R/update_vb.R:76-81).  Y may contain
     NaN (missing); X must be complete and standardised.  ``inner``: "c" = C
     restatement of src/coreLoop.cpp, "pure" = Python restatement of the
     reference's pure-R inner update in the same natural order (tiny cases).
@@ -436,7 +482,8 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_
     X = _F(X)
     n, p = X.shape
     q = Y.shape[1]
-    assert df == 1
+    assert df in (1, 3) and scheme in ("global_local", "global")
+    assert df == 1 or anneal is None
 
     if np.isnan(Y).any():                                                             # :19-32
         mis_pat = np.where(np.isnan(Y), 0.0, 1.0)
@@ -543,24 +590,38 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_
         m2_beta = update_m2_beta_(gam_vb, mu_beta_vb, sig2_beta_vb)                   # :235
         Z = update_Z_(gam_vb, theta_plus_zeta_vb, log_1mPhi, log_Phi, c=c)            # :237
 
-        L_vb = c_s * sig02_inv_vb * shr_fac_inv * (theta_vb ** 2 + sig2_theta_vb - 2 * theta_vb * m0
-                                                   + m0 ** 2) / 2 / df                # :241
-        rho_xi_inv_vb = c_s * (A2_inv + sig02_inv_vb)                                 # :242
         lentz_iters = 0
-        if annealing and anneal_scale:                                                # :244-254
-            lam2_inv_vb = update_annealed_lam2_inv_vb_(L_vb, c_s, df)
+        if scheme == "global":                                                        # R/atlasqtl_global_core.R:238-256
+            sig2_theta_vb = update_sig2_c0_vb_(q, 1 / sig02_inv_vb / shr_fac_inv, c=c)            # :240 (a scalar)
+            theta_vb = update_theta_vb_(Z, m0, sig02_inv_vb * shr_fac_inv, sig2_theta_vb, zeta_vb, c=c)   # :242
+            zeta_vb = update_zeta_vb_(Z, theta_vb, n0, sig2_zeta_vb, t02_inv, c=c)                # :245
+            nu_s0_vb = c_s * (0.5 + p / 2) - c_s + 1                                              # :252 (nu_s0 = rho_s0 = 1/2, :96)
+            rho_s0_vb = c_s * (0.5 + np.sum(sig2_theta_vb + theta_vb ** 2 - 2 * theta_vb * m0 + m0 ** 2) / 2)   # :253
+            sig02_inv_vb = float(nu_s0_vb / rho_s0_vb)                                            # :255
+            L_vb = lam2_inv_vb = Q_app = None
+            nu_xi_inv_vb = rho_xi_inv_vb = xi_inv_vb = None
         else:
-            Q_app, lentz_iters = Q_approx_vec(L_vb, return_iters=True)
-            lam2_inv_vb = 1 / (Q_app * L_vb) - 1
-        xi_inv_vb = nu_xi_inv_vb / rho_xi_inv_vb                                      # :276
-        sig2_theta_vb = update_sig2_c0_vb_(q, 1 / (sig02_inv_vb * lam2_inv_vb * shr_fac_inv), c=c)   # :278
-        theta_vb = update_theta_vb_(Z, m0, sig02_inv_vb * lam2_inv_vb * shr_fac_inv, sig2_theta_vb,
-                                    zeta_vb, c=c)                                     # :280
-        nu_s0_vb = update_nu_vb_(0.5, p, c=c_s)                                       # :283
-        rho_s0_vb = c_s * (xi_inv_vb + np.sum(lam2_inv_vb * shr_fac_inv
-                                              * (theta_vb ** 2 + sig2_theta_vb - 2 * theta_vb * m0 + m0 ** 2)) / 2)
-        sig02_inv_vb = float(nu_s0_vb / rho_s0_vb)                                    # :288
-        zeta_vb = update_zeta_vb_(Z, theta_vb, n0, sig2_zeta_vb, t02_inv, c=c)        # :290
+            L_vb = c_s * sig02_inv_vb * shr_fac_inv * (theta_vb ** 2 + sig2_theta_vb - 2 * theta_vb * m0
+                                                       + m0 ** 2) / 2 / df                # :241
+            rho_xi_inv_vb = c_s * (A2_inv + sig02_inv_vb)                                 # :242
+            if annealing and anneal_scale:                                                # :244-254
+                lam2_inv_vb = update_annealed_lam2_inv_vb_(L_vb, c_s, df)
+            else:
+                Q_app, lentz_iters = Q_approx_vec(L_vb, return_iters=True)
+                if df == 1:
+                    lam2_inv_vb = 1 / (Q_app * L_vb) - 1                                # :254
+                else:                                                                 # df == 3, :258
+                    lam2_inv_vb = np.exp(-np.log(3) - np.log(L_vb) + np.log(1 - L_vb * Q_app)
+                                         - np.log(Q_app * (1 + L_vb) - 1)) - 1 / 3
+            xi_inv_vb = nu_xi_inv_vb / rho_xi_inv_vb                                      # :276
+            sig2_theta_vb = update_sig2_c0_vb_(q, 1 / (sig02_inv_vb * lam2_inv_vb * shr_fac_inv), c=c)   # :278
+            theta_vb = update_theta_vb_(Z, m0, sig02_inv_vb * lam2_inv_vb * shr_fac_inv, sig2_theta_vb,
+                                        zeta_vb, c=c)                                     # :280
+            nu_s0_vb = update_nu_vb_(0.5, p, c=c_s)                                       # :283
+            rho_s0_vb = c_s * (xi_inv_vb + np.sum(lam2_inv_vb * shr_fac_inv
+                                                  * (theta_vb ** 2 + sig2_theta_vb - 2 * theta_vb * m0 + m0 ** 2)) / 2)
+            sig02_inv_vb = float(nu_s0_vb / rho_s0_vb)                                    # :288
+            zeta_vb = update_zeta_vb_(Z, theta_vb, n0, sig2_zeta_vb, t02_inv, c=c)        # :290
         theta_plus_zeta_vb = theta_vb[:, None] + zeta_vb[None, :]                     # :293-295
         log_Phi = _F(sp.log_ndtr(theta_plus_zeta_vb))
         log_1mPhi = _F(sp.log_ndtr(-theta_plus_zeta_vb))
@@ -576,12 +637,18 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_
                 annealing = False
         else:
             if it <= it_init + 1 or it % batch_conv == 0 or it % batch_conv == 1:     # :342
-                lb_new = elbo_global_local_(Y, A2_inv, beta_vb, df, eta, gam_vb, kappa, L_vb, lam2_inv_vb,
-                                            log_1mPhi, log_Phi, m0, m2_beta, n0, nu, nu_s0_vb, nu_xi_inv_vb,
-                                            Q_app, rho, rho_s0_vb, rho_xi_inv_vb, shr_fac_inv, sig02_inv_vb,
-                                            sig2_beta_vb, sig2_inv_vb, sig2_theta_vb, sig2_zeta_vb, t02_inv,
-                                            tau_vb, theta_vb, vec_sum_log_det_zeta, xi_inv_vb, zeta_vb,
-                                            X_norm_sq, Y_norm_sq, cp_Y_X, cp_X_Xbeta, mis_pat)
+                if scheme == "global":                                                # R/atlasqtl_global_core.R:283-291
+                    lb_new = elbo_global_(Y, beta_vb, eta, gam_vb, kappa, log_1mPhi, log_Phi, m0, m2_beta, n0, nu, 0.5,
+                                          nu_s0_vb, rho, 0.5, rho_s0_vb, shr_fac_inv, sig02_inv_vb, sig2_beta_vb,
+                                          sig2_inv_vb, sig2_theta_vb, sig2_zeta_vb, t02_inv, tau_vb, theta_vb,
+                                          vec_sum_log_det_zeta, zeta_vb, X_norm_sq, Y_norm_sq, cp_Y_X, cp_X_Xbeta, mis_pat)
+                else:
+                    lb_new = elbo_global_local_(Y, A2_inv, beta_vb, df, eta, gam_vb, kappa, L_vb, lam2_inv_vb,
+                                                log_1mPhi, log_Phi, m0, m2_beta, n0, nu, nu_s0_vb, nu_xi_inv_vb,
+                                                Q_app, rho, rho_s0_vb, rho_xi_inv_vb, shr_fac_inv, sig02_inv_vb,
+                                                sig2_beta_vb, sig2_inv_vb, sig2_theta_vb, sig2_zeta_vb, t02_inv,
+                                                tau_vb, theta_vb, vec_sum_log_det_zeta, xi_inv_vb, zeta_vb,
+                                                X_norm_sq, Y_norm_sq, cp_Y_X, cp_X_Xbeta, mis_pat)
                 rec["lb"] = lb_new
                 if debug and lb_new + eps < lb_old:                                   # :359-360
                     raise ElboNotMonotone("ELBO not increasing monotonically. Exit. "
@@ -605,8 +672,12 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_
                    sig2_beta_vb=np.array(sig2_beta_vb), sig2_inv_vb=float(sig2_inv_vb),
                    sig2_theta_vb=sig2_theta_vb, sig2_zeta_vb=float(sig2_zeta_vb), tau_vb=tau_vb,
                    eta_vb=eta_vb, kappa_vb=kappa_vb, nu_vb=float(nu_vb), rho_vb=float(rho_vb),
-                   nu_s0_vb=float(nu_s0_vb), rho_s0_vb=float(rho_s0_vb), xi_inv_vb=float(xi_inv_vb),
+                   nu_s0_vb=float(nu_s0_vb), rho_s0_vb=float(rho_s0_vb),
+                   xi_inv_vb=None if xi_inv_vb is None else float(xi_inv_vb),
                    L_vb=L_vb, cp_X_Xbeta=np.array(cp_X_Xbeta))
+        if scheme == "global":
+            out["sig2_theta_vb"] = np.full(p, float(sig2_theta_vb))      # the reference returns the scalar; one value per predictor here
+            out["lam2_inv_vb"] = np.ones(p)
     return out
 
 

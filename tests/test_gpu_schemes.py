@@ -1,0 +1,64 @@
+"""GPU: the other drivers over the same sweep against the oracle's restatements:
+  * the global-only core atlasqtl_global_core_ (R/atlasqtl_global_core.R:117-320, ELBO :372-421), with and without annealing,
+    complete and incomplete Y;
+  * the horseshoe with df = 3 (R/atlasqtl_global_local_core.R:258, R/elbo.R:95-105), without annealing."""
+import numpy as np
+import pytest
+
+from tests.util import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(ref, got, tr):
+    assert got["it"] == ref["it"] and got["converged"] == ref["converged"]
+    lref = np.array([r["lb"] for r in tr if r["lb"] is not None])
+    np.testing.assert_allclose(got["elbo_trace"][1], lref, rtol=1e-9)
+    assert np.all(np.diff(got["elbo_trace"][1]) > -1.5e-8)
+    np.testing.assert_allclose(got["mu_beta_vb"], ref["mu_beta_vb"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], atol=1e-9)
+    np.testing.assert_allclose(got["theta_vb"], ref["theta_vb"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(got["zeta_vb"], ref["zeta_vb"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(got["sig2_theta_vb"], ref["sig2_theta_vb"], rtol=1e-9)
+    np.testing.assert_allclose(got["sig02_inv_vb"], ref["sig02_inv_vb"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("anneal", [None, (1, 2, 10), (3, 2, 4)])
+@pytest.mark.parametrize("shape,na", [((100, 75, 20), 0.0), ((300, 130, 49), 0.0), ((200, 90, 33), 0.08)])
+def test_global_only_core_matches_oracle(shape, na, anneal):
+    import atlasqtl_amd as A
+    from oracle import atlasqtl_oracle as O
+    n, p, q = shape
+    prob = make_problem(n, p, q, p_act=8, prob_assoc=1.0 if q <= 20 else 0.3, na_frac=na)
+    li = {k: v for k, v in prob["list_init"].items() if k != "sig2_theta_vb"}       # that core has no local scales
+    tr = []
+    ref = O.atlasqtl_global_core_(prob["Y"], prob["X"], q, anneal, 1, 0.1, 1000, prob["list_hyper"], dict(li, sig2_theta_vb=np.ones(prob["p"])),
+                                  trace=tr, full_output=True)
+    got = A.atlasqtl_global_core_(prob["Y"], prob["X"], q, anneal, 1, 0.1, 1000, 0, prob["list_hyper"], li, full_output=True, debug=True)
+    _compare(ref, got, tr)
+    np.testing.assert_array_equal(got["lam2_inv_vb"], 1.0)
+
+
+@pytest.mark.parametrize("shape,na", [((100, 75, 20), 0.0), ((300, 130, 49), 0.0), ((200, 90, 33), 0.08), ((1000, 208, 40), 0.0)])
+def test_horseshoe_df3_matches_oracle(shape, na):
+    import atlasqtl_amd as A
+    from oracle import atlasqtl_oracle as O
+    n, p, q = shape
+    prob = make_problem(n, p, q, p_act=8, prob_assoc=1.0 if q <= 20 else 0.3, na_frac=na)
+    tr = []
+    ref = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, None, 3, 0.1, 1000, prob["list_hyper"], prob["list_init"], trace=tr,
+                                        full_output=True)
+    got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, None, 3, 0.1, 1000, 0, prob["list_hyper"], prob["list_init"],
+                                        full_output=True, debug=True)
+    _compare(ref, got, tr)
+    np.testing.assert_allclose(got["lam2_inv_vb"], ref["lam2_inv_vb"], rtol=1e-6)
+
+
+def test_unsupported_variants_fail_loudly():
+    import atlasqtl_amd as A
+    from atlasqtl_amd._lib import AtlasqtlHipError
+    prob = make_problem(100, 40, 8, p_act=4, prob_assoc=1.0)
+    with pytest.raises(AtlasqtlHipError, match="Kummer"):
+        A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 8, (1, 2, 10), 3, 0.1, 10, 0, prob["list_hyper"], prob["list_init"])
+    with pytest.raises(NotImplementedError, match="df must be 1 or 3"):
+        A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 8, None, 5, 0.1, 10, 0, prob["list_hyper"], prob["list_init"])
