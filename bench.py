@@ -37,8 +37,9 @@ PEAK_FP64_MFMA_MEASURED_TFLOPS = 77.8
 # HBM-side bytes of ONE core-sweep launch at the default workload on one GPU, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command with the gfx950
 # correction (FETCH_SIZE x 2 for coalesced streaming reads, calibrated on aq_k_prepass's gam read):
-# profiles/r01_pmc_hbm_traffic_v6.txt.  PMC counters cannot be read from inside the timed run.
-PMC_TRAFFIC_C3_BYTES = 4.11e10
+# profiles/r02_pmc_hbm_traffic_v1.txt (reads 2 x 11,625,797 KB + writes 8,428,673 KB).  PMC counters cannot be read from inside
+# the timed run, so this is the profile's number for the same kernel and workload, not a value measured in this run.
+PMC_TRAFFIC_C3_BYTES = 3.24e10
 
 
 def build_problem(n, p, q_total, k0, k1, device, seed=123):
@@ -287,7 +288,7 @@ def main():
                                                      3: "aq_core_sweep_mis_kernel"}[st1["core_kernel"]], "achieved": achieved,
                          "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,
                          "traffic": PMC_TRAFFIC_C3_BYTES if (n, p, q, world) == (1000, 50000, 10000, 1) else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic_v6.txt)",
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC passes of the same command, profiles/r02_pmc_hbm_traffic_v1.txt: a profile constant, not measured in this run)",
                          "algorithmic_bytes": 32.0 * p * q_loc + 8.0 * n * p + 16.0 * n * q_loc,
                          "peak_measured_mfma_f64": PEAK_FP64_MFMA_MEASURED_TFLOPS,
                          "frac_of_measured_mfma_peak": achieved / PEAK_FP64_MFMA_MEASURED_TFLOPS,
