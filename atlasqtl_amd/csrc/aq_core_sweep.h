@@ -54,6 +54,13 @@ struct AqCoreArgs {
   int stagger;           // look-ahead kernel: matrix waves 4-6 start a phase when their SIMD partner has issued this many tiles (0 = off)
   int *done;             // chained segments: done[group] = number of that group's segments already finished
   int *errflag;          // set when a bounded wait on done[] expires (results invalid, reported to the host)
+  // sample split of the look-ahead kernel (n beyond one workgroup's registers): C workgroups share a trait group, workgroup
+  // k*C + part holds the residual rows [part, part + 1) * n_pad / C.  Per SNP block each publishes its partial S' and adds the
+  // others' in fixed order before running the SAME chain (bitwise identical delta in all parts)
+  int C;                 // parts per trait group (1 = no split)
+  double *Pbuf;          // [nwg][2][C][256 TT] partial S' of each part, double-buffered by block parity
+  int *pflag;            // [nwg][C] number of blocks whose partial S' this part has published
+  double *rnpart;        // [C][q_pad] partial ||R_k||^2 of each part
   long long *dbg;        // -DAQ_DIAG_TIME builds only: per (workgroup, wave) cycles spent waiting / in total (tools/prof_roles.sh)
   const double *theta;   // look-ahead kernel (fused pre-pass): theta_vb [p_pad], zeta_vb [q_pad] of this sweep
   const double *zeta;

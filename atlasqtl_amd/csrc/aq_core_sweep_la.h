@@ -137,7 +137,12 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       __syncthreads();
     }
   }
-  const int wg = wg_;
+  // sample split (C > 1, never together with SEG): workgroup k*C + part = part of trait group k -- partners are adjacent in
+  // dispatch order, so a waiting part always has its partners resident or next to be dispatched
+  const int C = SEG ? 1 : a.C;
+  const int part = C > 1 ? wg_ % C : 0;
+  const int wg = C > 1 ? wg_ / C : wg_;
+  const bool lead = (part == 0);                // the part that records the group's results
   const int tile0 = wg * TT;                    // first 16-trait tile of this workgroup
   const int nblk = seg_b1 - seg_b0;
   const bool helper = (w == 7);
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     constexpr int ROLE = decltype(rolec)::value;
     constexpr bool HI = ROLE == 0;
     constexpr int ST = (NTC + 2) / 3;              // stagger: the SIMD partner enters the phase after this many tiles
-    const int my_t0 = ROLE == 0 ? mw * NT : ROLE == 1 ? 3 * NT + (mw - 3) * NT2 : 3 * (NT + NT2);
+    const int my_t0 = part * NTT + (ROLE == 0 ? mw * NT : ROLE == 1 ? 3 * NT + (mw - 3) * NT2 : 3 * (NT + NT2));
     const int slot = ROLE == 2 ? NWM : mw;         // partial S' slot; progress counter: Fl[mw], the recurrence wave's is Fl[11]
     // residual tiles: Rr[tt][t][r] <-> sample 16*(my_t0+t) + 4 r + g, trait col of tile tile0 + tt   (f64 MFMA D layout
     // row = 4 reg + (lane >> 4): the host refuses to run this kernel on a device that reports the other map)
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     // X operand streams: [nb][NTT][2][64] x 16 B; this wave's tiles start at my_t0, lane address = block base + voff
     const unsigned voff = (unsigned)((my_t0 * 128 + lane) * 16);
     const char *XUb = (const char *)a.XU, *XAb = (const char *)a.XA;
-    constexpr long long BLK = (long long)NTT * 128 * 16;   // bytes per SNP block
+    const long long BLK = (long long)NTT * C * 128 * 16;   // bytes per SNP block (all parts)
     aq_v2 p0, p1, q0, q1, c0, c1, d0, d1;   // XU tiles alternate between (p0,p1) and (q0,q1), XA tiles between (c0,c1) and (d0,d1)
     // Tile step t: U(t) = 4 TT MFMAs chained on Rr[.][t]; S(t-1) = 4 TT chained on acc, whose B operand Rr[.][t-1] was
     // finished a whole step earlier.  Loads, all issued at the START of a step: XU(t+1) (used one step later) and XA(t)
@@ -399,6 +404,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const double rc_cinv2s = a.c * a.inv2s[ktrait];
       const double rc_cst = a.cst[ktrait];
       const double rc_K = rc_coef * rc_coef * rc_cinv2s;   // keeps mu off the dependency chain of the recursion
+      bool split_dead = false;   // a bounded wait on a partner expired (reported through errflag)
       auto chain_block = [&](int b) __attribute__((always_inline)) {
         const int par = b & 1;
         {   // block b needs its six partial S' and its staged scalars
@@ -420,6 +426,41 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #pragma unroll
           for (int ww = 1; ww < NPS; ww++) sv += Sp[par][ww][j * NTR + ht];
           Sown[r] = sv;
+        }
+        if (C > 1) {
+          // ---- sample split: publish this part's partial S', collect the others', add in fixed order ----
+          // All exchanged words are agent-scope atomics (sc1: written through to, and read from, the level the XCDs share),
+          // ordered by program order + s_waitcnt.  No release / acquire fence: at agent scope it would write back and
+          // invalidate this XCD's whole L2, where the X operand panels live.
+          const int kdone = b - seg_b0 + 1;
+          double *slot = a.Pbuf + ((size_t)(wg * 2 + par) * C) * ENT + lane;
+#pragma unroll
+          for (int r = 0; r < RPG; r++)
+            __hip_atomic_store(&slot[(size_t)part * ENT + 64 * r], Sown[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial is performed before the flag goes up
+          if (lane == 0) __hip_atomic_store(&a.pflag[wg * C + part], kdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while (!split_dead) {   // lane c polls part c's flag
+            int f = kdone;
+            if (lane < C && lane != part) f = __hip_atomic_load(&a.pflag[wg * C + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(f >= kdone)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) { *a.errflag = 1; split_dead = true; }   // give up for good: results are invalid
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // flags observed before the partials are requested
+          double tot[RPG];
+#pragma unroll
+          for (int r = 0; r < RPG; r++) tot[r] = 0.0;
+          for (int c2 = 0; c2 < C; c2++) {
+            double pv[RPG];
+#pragma unroll
+            for (int r = 0; r < RPG; r++)
+              pv[r] = __hip_atomic_load(&slot[(size_t)c2 * ENT + 64 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int r = 0; r < RPG; r++) tot[r] += (c2 == part) ? Sown[r] : pv[r];
+          }
+#pragma unroll
+          for (int r = 0; r < RPG; r++) Sown[r] = tot[r];
         }
         if (b > seg_b0) {
           // cross-block correction X_b'X_{b-1} delta_{b-1} of this group's rows (a segment starts from a complete residual)
@@ -537,8 +578,10 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         const int e = lane + 64 * r, hj = hg + NG * r;
         const double gm = Lgam[par][e], mu = Lmu[par][e];
         const size_t off = tbase + (size_t)(16 * b + hj) * 16;
-        a.gam[off] = gm;
-        a.mu[off] = mu;
+        if (lead) {
+          a.gam[off] = gm;
+          a.mu[off] = mu;
+        }
         const int j = 16 * b + hj;
         double gb = 0.0;
         if (kvalid && j < a.p) {
@@ -550,7 +593,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           cs3 += gb;
         }
         gb = aq_row16_sum(gb);                      // over the 16 traits of the tile (one DPP row)
-        if ((ht & 15) == 0) a.rowGB[(size_t)(tile0 + (ht >> 4)) * a.p_pad + j] = gb;
+        if ((ht & 15) == 0 && lead) a.rowGB[(size_t)(tile0 + (ht >> 4)) * a.p_pad + j] = gb;
       }
     };
     if (a.mode == 1) {
@@ -619,8 +662,9 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     double r2 = 0.0;
     for (int s = 0; s < NPS * 4; s++) r2 += Lrn[s][tid];
     double *sm = a.sums + (size_t)seg * 5 * a.q_pad;
-    sm[(size_t)4 * a.q_pad + k2] = r2;
-    for (int v = 0; v < 4; v++) {
+    if (C > 1) a.rnpart[(size_t)part * a.q_pad + k2] = r2;   // added over the parts by aq_k_sum_parts
+    else sm[(size_t)4 * a.q_pad + k2] = r2;
+    for (int v = 0; v < 4 && lead; v++) {
       double acc2 = 0.0;
       for (int jj = 0; jj < NG; jj++) acc2 += Lred[v][jj * NTR + tid];
       sm[(size_t)v * a.q_pad + k2] = acc2;

@@ -144,6 +144,7 @@ struct aq_vb {
   double *coef = nullptr, *inv2s = nullptr, *cst = nullptr, *sums = nullptr, *rowA = nullptr, *rowGB = nullptr;
   double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
   bool use_la = false;   // look-ahead kernel (aq_core_sweep_la.h)
+  int laC = 1;           // look-ahead kernel: workgroups (sample parts) per trait group, n > 1056
   int TT = 1;            // look-ahead kernel: 16-trait tiles per workgroup (2 when there are enough tiles to fill the chip)
   int stagger = 0;       // look-ahead kernel: tile at which a matrix wave releases its SIMD partner into the phase (0 = off)
   int NT2 = 0;           // look-ahead kernel: tiles of matrix waves 4,5,6 (NT: waves 0,1,2)
@@ -306,6 +307,8 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   } else if (s->use_la) {
     const unsigned nwg = (unsigned)(s->ntile / s->TT);
     a.done = s->done; a.errflag = s->errflag; a.stagger = s->stagger;
+    a.C = s->laC; a.Pbuf = s->Pbuf; a.pflag = s->pflag; a.rnpart = s->rnpart;
+    if (s->laC > 1) AQ_HIP(hipMemsetAsync(s->pflag, 0, (size_t)s->ntile * s->laC * sizeof(int), 0));
     a.dbg = nullptr;
     static long long *dbg_buf = nullptr;   // AQ_DIAG_DUMP=<file> with a -DAQ_DIAG_TIME build: per-role wait / total cycles of sweep 15
     const char *dump = getenv("AQ_DIAG_DUMP");
@@ -319,11 +322,13 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     a.nseg = chained ? s->chain : 1;
     if (chained) AQ_HIP(hipMemsetAsync(s->done, 0, (size_t)s->ntile * sizeof(int), 0));
     // chained-segment launch: chain * nwg workgroups, workgroup s*nwg + k = SNP segment s of trait-tile group k
-    const unsigned grid = chained ? (unsigned)((long long)s->chain * nwg) : nwg;
+    const unsigned grid = chained ? (unsigned)((long long)s->chain * nwg) : nwg * (unsigned)s->laC;
     int lrc = s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
     if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
     if (chained)
       hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
+    if (s->laC > 1)
+      hipLaunchKernelGGL(aq_k_sum_parts, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->rnpart, s->sums + (size_t)4 * s->q_pad, s->laC, s->q_pad);
     if (a.dbg && s->it == 15) {
       AQ_HIP(hipDeviceSynchronize());
       std::vector<long long> h((size_t)grid * 24);
@@ -440,7 +445,8 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       }
     }
     // the masked MFMA kernel also serves complete Y beyond the look-ahead kernel's n (all-ones mask, empty lists)
-    if ((has_missing || pr->n > 1056) && pr->n <= 16384 && max_missing <= AQ_MIS_MMAX && !(ek && atoi(ek) == 2)) {
+    const bool la_split_ok = !has_missing && pr->n > 1056 && pr->n <= 8 * 16 * 105 && !(ek && atoi(ek) >= 2);   // complete Y, large n
+    if ((has_missing || (pr->n > 1056 && !la_split_ok)) && pr->n <= 16384 && max_missing <= AQ_MIS_MMAX && !(ek && atoi(ek) == 2)) {
       s->use_mis = true;
       s->NW = 8;
       // n_pad = 128 NT C: C workgroups per trait tile, NT in {1,2,4,8,16} residual tiles per wave.  Model of a sweep:
@@ -466,7 +472,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       }
       s->Mmax = (max_missing + 15) / 16 * 16;
       if (s->Mmax < 16) s->Mmax = 16;
-    } else if (has_missing || (ek && atoi(ek) == 2) || pr->n > 1056) {
+    } else if (has_missing || (ek && atoi(ek) == 2) || (pr->n > 1056 && !la_split_ok)) {
       // generic kernel geometry: n_pad = 64 * NE * WPT samples, WPT waves (and workgroups) per trait (tile)
       s->use_tw = true;
       s->WPT = pr->n <= 2048 ? 1 : pr->n <= 5120 ? 2 : 4;
@@ -495,20 +501,43 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         // smallest geometry that holds ntiles: NT in 1..11, NT2 in {NT, NT - 1}, plus the recurrence wave's aq_la_nt3 tiles;
         // among equals the one with more tiles on the recurrence wave (AQ_NT3=0/3/6 pins its tile count for experiments)
         const char *e3 = getenv("AQ_NT3");
-        int best_tiles = 1 << 30, best_nt3 = -1;
-        for (int NT = 1; NT <= 11; NT++)
-          for (int NT2 = NT; NT2 >= (NT > 1 ? NT - 1 : NT); NT2--) {
-            const int nt3 = aq_la_nt3(NT, NT2, s->TT), tiles = 3 * (NT + NT2) + nt3;
-            if (tiles < ntiles || (e3 && atoi(e3) != nt3 && s->TT == 2 && NT >= 8)) continue;
-            if (tiles < best_tiles || (tiles == best_tiles && nt3 > best_nt3)) { best_tiles = tiles; best_nt3 = nt3; s->NT = NT; s->NT2 = NT2; }
+        auto fit = [&](int tiles_needed, int nt_max, int *NTo, int *NT2o) {
+          int best_tiles = 1 << 30, best_nt3 = -1;
+          for (int NT = 1; NT <= nt_max; NT++)
+            for (int NT2 = NT; NT2 >= (NT > 1 ? NT - 1 : NT); NT2--) {
+              const int nt3 = aq_la_nt3(NT, NT2, s->TT), tiles = 3 * (NT + NT2) + nt3;
+              if (tiles < tiles_needed || (e3 && atoi(e3) != nt3 && s->TT == 2 && NT >= 8)) continue;
+              if (tiles < best_tiles || (tiles == best_tiles && nt3 > best_nt3)) { best_tiles = tiles; best_nt3 = nt3; *NTo = NT; *NT2o = NT2; }
+            }
+          return best_tiles;
+        };
+        if (pr->n <= 1056 && !getenv("AQ_LA_C")) {
+          s->laC = 1;
+          s->n_pad = 16 * fit(ntiles, 11, &s->NT, &s->NT2);      // n <= 1056 always fits (11, 11)
+        } else {
+          // n beyond one workgroup's registers: C workgroups share a trait group (sample split, one tile per workgroup).  Cost of
+          // a sweep ~ rounds of workgroups x time per SNP block: the MFMA stream of one SIMD (0.213 us per residual tile) or the
+          // exchange + chain (~8 us), whichever is longer.  (AQ_LA_C forces the split at small n: test hook.)
+          s->TT = 1; s->q_pad = (pr->q + 15) / 16 * 16; s->ntile = s->q_pad / 16; s->stagger = 0;
+          double best = 1e300;
+          const char *ec = getenv("AQ_LA_C");
+          for (int C = 2; C <= 8; C++) {
+            if (ec && atoi(ec) != C) continue;
+            int NT = 0, NT2 = 0;
+            const int tiles = fit((ntiles + C - 1) / C, 18, &NT, &NT2);
+            if (tiles >= (1 << 30)) continue;
+            const double rounds = (double)(((long long)s->ntile * C + s->ncu - 1) / s->ncu);
+            const double cost = rounds * std::max(0.213 * (NT + NT2) + 1.0, 8.0);
+            if (cost < best - 1e-9) { best = cost; s->laC = C; s->NT = NT; s->NT2 = NT2; s->n_pad = 16 * tiles * C; }
           }
-        s->n_pad = 16 * best_tiles;                              // n <= 1056 always fits (11, 11)
+          if (best >= 1e300) { delete s; return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead geometry for this n"); }
+        }
         if (s->TT == 2) s->stagger = (s->NT + 2) / 3;
       }
       if (const char *e = getenv("AQ_STAGGER")) s->stagger = atoi(e) >= 0 ? atoi(e) : 0;
       // more workgroups than CUs: chained SNP segments even out the last round (3 rounds -> ~2.5 for 625 workgroups)
       const int nwg = s->ntile / s->TT;
-      if (nwg > s->ncu) {
+      if (nwg > s->ncu && s->laC == 1) {
         double best = 1e30;
         for (int S = 2; S <= 16; S++) {   // rounds of workgroups per sweep, in units of whole-sweep rounds
           long long wg = (long long)nwg * S;
@@ -520,6 +549,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       if (const char *e = getenv("AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
       if (s->chain > s->nb) s->chain = s->nb;
       if (s->chain > 32) s->chain = 32;
+      if (s->laC > 1) s->chain = 0;   // the parts of a group must be co-resident: no chained segments
     }
   }
   if (s->use_mis && s->misC == 1) {   // same chained-segment choice as for the look-ahead kernel
@@ -592,6 +622,11 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     }
     AQ_HIPF(hipMemcpy(s->midx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     AQ_HIPF(hipMemcpy(s->mcnt4, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  if (s->use_la && s->laC > 1) {
+    AQ_TRYF(aq_dalloc(&s->Pbuf, (size_t)s->ntile * 2 * s->laC * 256));
+    AQ_TRYF(aq_dalloc(&s->pflag, (size_t)s->ntile * s->laC));
+    AQ_TRYF(aq_dalloc(&s->rnpart, (size_t)s->laC * s->q_pad));
   }
   AQ_TRYF(aq_dalloc(&s->R, (size_t)s->ntile * s->n_pad * 16));
   AQ_TRYF(aq_dalloc(&s->gam, (size_t)s->ntile * s->p_pad * 16));
@@ -815,13 +850,13 @@ static int aq_elbo_local(aq_vb *s) {
 // partners' partial S) raise errflag when they expire: the results of that launch are invalid.  Polled wherever results
 // leave the library: ELBO evaluation, end of a run, status, state and result getters.
 static int aq_check_chain_error(aq_vb *s) {
-  if (!s->errflag || (s->chain <= 1 && s->misC <= 1 && !s->errflag_forced)) return AQ_OK;
+  if (!s->errflag || (s->chain <= 1 && s->misC <= 1 && s->laC <= 1 && !s->errflag_forced)) return AQ_OK;
   int f = 0;
   AQ_HIP(hipMemcpy(&f, s->errflag, sizeof(int), hipMemcpyDeviceToHost));
   if (f != 0) {
     s->failed = true;
     s->fail_code = AQ_ERR_DEVICE;
-    s->fail_msg = s->misC > 1 ? "core sweep: a bounded wait on a partner workgroup's partial sums expired (results invalid)"
+    s->fail_msg = (s->misC > 1 || s->laC > 1) ? "core sweep: a bounded wait on a partner workgroup's partial sums expired (results invalid)"
                               : "chained core sweep: a bounded wait on a tile's previous SNP segment expired (results invalid; set AQ_CHAIN=0)";
     return aq_fail(AQ_ERR_DEVICE, s->fail_msg);
   }

@@ -138,13 +138,26 @@ def test_generic_kernel_split_traits_matches_oracle(shape, na, wpt, monkeypatch)
     _check_against_oracle(make_problem(n, p, q, p_act=8, prob_assoc=0.3, na_frac=na), q)
 
 
-@pytest.mark.parametrize("shape,na", [((2500, 40, 20), 0.05), ((5000, 24, 17), 0.05), ((5200, 20, 9), 0.0)])
-def test_large_n_matches_oracle(shape, na):
-    """n beyond one workgroup's registers (C5 has n = 5000 and a missingness mask): the masked MFMA kernel with the
-    sample axis split over 5 / 5 / 3 cooperating workgroups per trait tile; complete Y takes the same kernel."""
+@pytest.mark.parametrize("shape,na,kernel", [((2500, 40, 20), 0.05, 3), ((5000, 24, 17), 0.05, 3), ((5200, 20, 9), 0.0, 0),
+                                             ((2500, 40, 20), 0.0, 0), ((1100, 50, 33), 0.0, 0)])
+def test_large_n_matches_oracle(shape, na, kernel):
+    """n beyond one workgroup's registers (C5 has n = 5000 and a missingness mask): the sample axis split over cooperating
+    workgroups per trait tile -- the masked MFMA kernel with missing values, the look-ahead kernel (core_kernel 0: partial S'
+    exchanged by the recurrence waves, redundant chains) for complete Y."""
     from tests.util import make_problem
     n, p, q = shape
-    _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q, kernel=3)
+    _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q, kernel=kernel)
+
+
+@pytest.mark.parametrize("C", [2, 3, 5, 8])
+@pytest.mark.parametrize("shape", [(300, 130, 49), (200, 90, 33), (1000, 64, 17)])
+def test_look_ahead_kernel_sample_split_matches_oracle(shape, C, monkeypatch):
+    """The cross-workgroup exchange of the look-ahead kernel's partial S' (agent-scope stores + flags, the same chain run
+    redundantly in every part) forced at small n with AQ_LA_C."""
+    from tests.util import make_problem
+    monkeypatch.setenv("AQ_LA_C", str(C))
+    n, p, q = shape
+    _check_against_oracle(make_problem(n, p, q, p_act=8, prob_assoc=0.3), q, kernel=0)
 
 
 @pytest.mark.parametrize("shape,na", [((2500, 40, 20), 0.05), ((5000, 24, 17), 0.05)])
