@@ -61,6 +61,14 @@ struct AqCoreArgs {
   double *Pbuf;          // [nwg][2][C][256 TT] partial S' of each part, double-buffered by block parity
   int *pflag;            // [nwg][C] number of blocks whose partial S' this part has published
   double *rnpart;        // [C][q_pad] partial ||R_k||^2 of each part
+  // Y with missing values in the look-ahead kernel (MASK instances): the residual is re-masked after every update, and the
+  // Gram blocks of the recursion are the trait's own, X_b' diag(mis_k) X_b and X_b' diag(mis_k) X_{b-1}, precomputed once into
+  // HBM (they depend on X and the missingness pattern only): GK[tile][b] = { diag, lower triangle [136][16 traits] ;
+  // cross [16][16][16 traits] } = 6272 doubles
+  const double *mis;     // [ntile][n_pad][16] 1 = observed
+  const double *GK;
+  const double *tau, *log_tau;             // [q_pad]
+  const double *sig2_inv_p, *log_sig2_inv_p;   // scalars of this sweep (device memory: written by aq_k_qpre just before)
   long long *dbg;        // -DAQ_DIAG_TIME builds only: per (workgroup, wave) cycles spent waiting / in total (tools/prof_roles.sh)
   const double *theta;   // look-ahead kernel (fused pre-pass): theta_vb [p_pad], zeta_vb [q_pad] of this sweep
   const double *zeta;
@@ -71,6 +79,7 @@ struct AqCoreArgs {
 // Look-ahead kernel: 16-sample residual tiles owned by the RECURRENCE wave (on top of the 3 (NT + NT2) of the six matrix
 // waves).  With two trait tiles per workgroup a phase is long enough for that wave to run its chain and then some matrix
 // work on SIMD 3, which otherwise issues no MFMA at all.  Shared by the kernel template and the host's geometry.
+constexpr int AQ_GK_DIAG = 136 * 16, AQ_GK_STRIDE = 136 * 16 + 256 * 16;   // doubles per (tile, SNP block) of AqCoreArgs::GK
 constexpr int aq_la_nt3(int NT, int NT2, int TT) { return (TT == 2 && NT >= 8) ? (NT2 == NT ? 3 : 6) : 0; }
 
 __device__ __forceinline__ aq_d4 aq_mfma(double a, double b, aq_d4 c) {

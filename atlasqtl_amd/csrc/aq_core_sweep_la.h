@@ -101,8 +101,11 @@ __device__ __forceinline__ void aq_static_for(F &&f) {
 // k, starting from the residual that segment s-1 of the same group left in global memory.  Blocks are dispatched in
 // index order, so that workgroup has normally finished long before; correctness does not depend on it: the hand-off
 // is an agent-scope release (producer) / acquire (consumer) around done[k], and the wait is bounded.
-template <int NT, int NT2, bool SEG, int TT>
+// MASK: Y with missing values (reference coreDualMisLoop, src/coreLoop.cpp:91-138): masked residual, per-trait Gram blocks and
+// per-entry sig2_beta_vb, the NA forms of the column sums (six rows).  One trait tile per workgroup only.
+template <int NT, int NT2, bool SEG, int TT, bool MASK = false>
 __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
+  static_assert(!MASK || TT == 1, "the masked form keeps 16 per-trait Gram blocks in LDS: one trait tile per workgroup");
   constexpr int NWM = 6;                        // matrix waves: 0,1,2,4,5,6
   constexpr int NT3 = aq_la_nt3(NT, NT2, TT);       // residual tiles of the recurrence wave (its matrix work follows its chain)
   constexpr int NPS = NWM + (NT3 > 0 ? 1 : 0);  // partial S' slots
@@ -155,10 +158,15 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   __shared__ double Lm1[2][ENT];       // old m1 = gam*mu
   __shared__ double LB[2][ENT];        // slope b of Z
   __shared__ double Laa[2][ENT];       // intercept a of Z (Z = a + gam b, R/update_vb.R:217-234)
-  __shared__ double LG[2][512];        // X_b'X_b as [16][32], upper 16 columns zero
-  __shared__ double LGx[2][256];       // X_b'X_{b-1}  [j][i]
+  __shared__ double LG[MASK ? 1 : 2][MASK ? 1 : 512];    // X_b'X_b as [16][32], upper 16 columns zero        (complete Y)
+  __shared__ double LGx[MASK ? 1 : 2][MASK ? 1 : 256];   // X_b'X_{b-1}  [j][i]                              (complete Y)
+  // MASK: the traits' own blocks.  Diagonal block: lower triangle [i (i + 1) / 2 + j][trait], ONE buffer (the helper refills it
+  // between two chains, counter Fl[12]); cross block [j][i][trait], by block parity.  Per-entry constants of the chain.
+  __shared__ double LGk[MASK ? AQ_GK_DIAG : 1];
+  __shared__ double LGxk[MASK ? 2 : 1][MASK ? 4096 : 1];
+  __shared__ double Lcoef[2][MASK ? ENT : 1], LK[2][MASK ? ENT : 1], Ls2[2][MASK ? ENT : 1], Lls2[2][MASK ? ENT : 1];
   __shared__ double Lgam[2][ENT], Lmu[2][ENT], Ldel[2][ENT];
-  __shared__ double Lred[4][64];       // the helper lanes' column sums [row group][trait], added up per trait at the end
+  __shared__ double Lred[6][64];       // the helper lanes' column sums [row group][trait], added up per trait at the end
   __shared__ double Lrn[NPS * 4][NTR];
   // Point-to-point progress counters instead of a workgroup barrier per phase: Fl[0..5] = number of SNP blocks whose
   // partial S' matrix wave m has written, Fl[6] = blocks the recurrence wave has finished, Fl[7] = blocks the helper
@@ -203,11 +211,13 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const int e = lane + 64 * r;
       Ldel[0][e] = Ldel[1][e] = 0.0;   // read (times zero) by the matrix waves' first two phases
     }
+    if constexpr (!MASK) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int e = lane + 64 * r;
-      LG[0][(e >> 4) * 32 + 16 + (e & 15)] = 0.0;
-      LG[1][(e >> 4) * 32 + 16 + (e & 15)] = 0.0;
+      for (int r = 0; r < 4; r++) {
+        const int e = lane + 64 * r;
+        LG[0][(e >> 4) * 32 + 16 + (e & 15)] = 0.0;
+        LG[1][(e >> 4) * 32 + 16 + (e & 15)] = 0.0;
+      }
     }
   }
 
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     // residual tiles: Rr[tt][t][r] <-> sample 16*(my_t0+t) + 4 r + g, trait col of tile tile0 + tt   (f64 MFMA D layout
     // row = 4 reg + (lane >> 4): the host refuses to run this kernel on a device that reports the other map)
     aq_d4 Rr[TT][NTC];
+    unsigned long long mb0 = 0, mb1 = 0;   // MASK: bit 4 t + r = entry (tile t, register r) observed; tiles 16, 17 in mb1
     aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
       constexpr int tt = decltype(ttc)::value;
       const double *Rg = a.R + (size_t)(tile0 + tt) * a.n_pad * 16 + (size_t)(16 * my_t0 + g) * 16 + col;
@@ -238,8 +249,20 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         constexpr int t = decltype(tc)::value;
 #pragma unroll
         for (int r = 0; r < 4; r++) Rr[tt][t][r] = Rg[(16 * t + 4 * r) * 16];
+        if constexpr (MASK) {
+          const double *Mg = a.mis + (size_t)tile0 * a.n_pad * 16 + (size_t)(16 * my_t0 + g) * 16 + col;
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (Mg[(16 * t + 4 * r) * 16] != 0.0) { if (t < 16) mb0 |= 1ull << (4 * (t & 15) + r); else mb1 |= 1ull << (4 * (t & 15) + r); }
+        }
       });
     });
+    auto remask = [&](auto tc) __attribute__((always_inline)) {   // R_K = mis .* R_K for one residual tile (R/...core.R:19-22 in n-space)
+      constexpr int t = decltype(tc)::value;
+      const unsigned long long mb = t < 16 ? mb0 : mb1;
+#pragma unroll
+      for (int r = 0; r < 4; r++) Rr[0][t][r] = ((mb >> (4 * (t & 15) + r)) & 1ull) ? Rr[0][t][r] : 0.0;
+    };
     // X operand streams: [nb][NTT][2][64] x 16 B; this wave's tiles start at my_t0, lane address = block base + voff
     const unsigned voff = (unsigned)((my_t0 * 128 + lane) * 16);
     const char *XUb = (const char *)a.XU, *XAb = (const char *)a.XA;
@@ -313,6 +336,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         if (HI && a.stagger) signal(8 + mw, i + 1);
         __builtin_amdgcn_sched_barrier(0);
         AQ_LD2(p0, p1, voff, nxu);
+        if constexpr (MASK) remask(C0{});
         S(C0{}, c0, c1);
         __builtin_amdgcn_sched_barrier(0);
         AQ_LD2(c0, c1, voff, nxa);
@@ -345,6 +369,10 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
             if constexpr (last) { if constexpr (even) AQ_WAIT2(2, d0, d1); else AQ_WAIT2(2, c0, c1); }
             else if constexpr (t >= 2) { if constexpr (even) AQ_WAIT2(4, d0, d1); else AQ_WAIT2(4, c0, c1); }
             if constexpr (even) S(TP{}, d0, d1); else S(TP{}, c0, c1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (MASK) {   // behind S(t-1): the MFMA pipe works on that while U(t) completes
+            remask(tc);
             __builtin_amdgcn_sched_barrier(0);
           }
           if constexpr (last) {
@@ -400,9 +428,9 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   if (is_rec) {
     // =========================== recurrence wave ===========================================
     if (a.mode != 1) {   // (init mode: the helper wave hands beta to the matrix waves, nothing to do here)
-      const double rc_coef = a.coef[ktrait];
-      const double rc_cinv2s = a.c * a.inv2s[ktrait];
-      const double rc_cst = a.cst[ktrait];
+      const double rc_coef = MASK ? 0.0 : a.coef[ktrait];
+      const double rc_cinv2s = MASK ? 0.0 : a.c * a.inv2s[ktrait];
+      const double rc_cst = MASK ? 0.0 : a.cst[ktrait];
       const double rc_K = rc_coef * rc_coef * rc_cinv2s;   // keeps mu off the dependency chain of the recursion
       bool split_dead = false;   // a bounded wait on a partner expired (reported through errflag)
       auto chain_block = [&](int b) __attribute__((always_inline)) {
@@ -463,20 +491,60 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           for (int r = 0; r < RPG; r++) Sown[r] = tot[r];
         }
         if (b > seg_b0) {
-          // cross-block correction X_b'X_{b-1} delta_{b-1} of this group's rows (a segment starts from a complete residual)
+          // cross-block correction X_b'X_{b-1} delta_{b-1} of this group's rows (a segment starts from a complete residual);
+          // MASK: with the trait's own cross block X_b' diag(mis_k) X_{b-1}
           double dlp[16];
 #pragma unroll
           for (int i = 0; i < 16; i++) dlp[i] = Ldel[par ^ 1][i * NTR + ht];
 #pragma unroll
           for (int r = 0; r < RPG; r++) {
-            const double *gx = &LGx[par][(hg + NG * r) * 16];
             double cx = 0.0;
+            if constexpr (MASK) {
+              const double *gx = &LGxk[par][((hg + NG * r) * 16) * 16 + ht];
 #pragma unroll
-            for (int i = 0; i < 16; i++) cx += gx[i] * dlp[i];
+              for (int i = 0; i < 16; i++) cx += gx[i * 16] * dlp[i];
+            } else {
+              const double *gx = &LGx[par][(hg + NG * r) * 16];
+#pragma unroll
+              for (int i = 0; i < 16; i++) cx += gx[i] * dlp[i];
+            }
             Sown[r] -= cx;
           }
         }
         double sb = __shfl(Sown[0], ht, 64);     // S of SNP 0 (group 0) to every group
+        if constexpr (MASK) {
+          // ---- the same chain with the trait's own diagonal block (lower triangle in LGk) and per-entry sig2_beta_vb
+          // (src/coreLoop.cpp:115-133): coef, K and cA come per entry from the helper
+          wait_ge(12, b - seg_b0 + 1);             // the helper has put block b's diagonal blocks into the single LGk buffer
+          int rtri[RPG], rrow[RPG];
+#pragma unroll
+          for (int r = 0; r < RPG; r++) { rrow[r] = hg + NG * r; rtri[r] = rrow[r] * (rrow[r] + 1) / 2; }
+          double m1o = Lm1[par][ht], cA = LA[par][ht], cf = Lcoef[par][ht], ci = LK[par][ht], dj = LGk[ht];
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            const int jn = (j + 1) & 15;
+            const int en = jn * NTR + ht;
+            double m1o_n = Lm1[par][en], cA_n = LA[par][en], cf_n = Lcoef[par][en], ci_n = LK[par][en];
+            double d_n = LGk[(jn * (jn + 1) / 2 + jn) * 16 + ht];
+            const double g_next = LGk[(j < 15 ? (jn * (jn + 1) / 2 + j) : 0) * 16 + ht];   // G^(k)[j+1][j]
+            const double s_next = __shfl(Sown[jn / NG], (jn % NG) * NTR + ht, 64);
+            double s = sb + m1o * dj;                         // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1 (cp_X - cp_X_rm_k)(j,j))   :121
+            double mu = cf * s;                               // :125
+            double x = fma(-(s * s), ci, cA);                 // :127-129 with mu^2 = coef^2 s^2 (keeps mu off the chain)
+            double gm = aq_sigmoid_neg_fast(x);
+            double dl = gm * mu - m1o;                        // m1 - m1_old   :130
+            sb = s_next - g_next * dl;
+            // in-block part of :132, this group's rows (rows <= j are consumed: any finite factor will do for them)
+#pragma unroll
+            for (int r = (j / NG); r < RPG; r++) Sown[r] -= LGk[(rtri[r] + (rrow[r] < j ? rrow[r] : j)) * 16 + ht] * dl;
+            if (lane < NTR) {
+              Lgam[par][j * NTR + ht] = gm;
+              Lmu[par][j * NTR + ht] = mu;
+              Ldel[par][j * NTR + ht] = dl;
+            }
+            m1o = m1o_n; cA = cA_n; cf = cf_n; ci = ci_n; dj = d_n;
+          }
+        } else {
         double m1o = Lm1[par][ht], cA = a.c * (LA[par][ht] + rc_cst), dj = LG[par][0];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -500,6 +568,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
             Ldel[par][j * NTR + ht] = dl;
           }
           m1o = m1o_n; cA = cA_n; dj = d_n;
+        }
         }
         signal(6, b - seg_b0 + 1);   // delta, gam, mu of block b are in LDS
       };
@@ -529,21 +598,44 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       for (int r = 0; r < RPG; r++) th[r] = a.theta[16 * b + hg + NG * r];
     };
     // block b -> LDS parity par: loads first, the probit arithmetic covers their latency
+    // MASK: per-trait constants of the NA forms (src/coreLoop.cpp:108, R/update_vb.R:45) and this block's slice of GK
+    const double tau_k = MASK ? a.tau[ktrait] : 1.0;
+    const double sig2_inv_h = MASK ? *a.sig2_inv_p : 0.0;
+    const double cstna_k = MASK ? -(a.log_tau[ktrait] + *a.log_sig2_inv_p) / 2 : 0.0;
+    auto gk_block = [&](int b) __attribute__((always_inline)) { return a.GK + ((size_t)tile0 * a.nb + b) * AQ_GK_STRIDE; };
+    double dgr[MASK ? AQ_GK_DIAG / 64 : 1];   // diagonal blocks of the block being staged, on their way to the single LGk buffer
+    auto diag_load = [&](int b) __attribute__((always_inline)) {
+      const double *gk = gk_block(b);
+#pragma unroll
+      for (int i = 0; i < AQ_GK_DIAG / 64; i++) dgr[i] = gk[lane + 64 * i];
+    };
+    auto diag_commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < AQ_GK_DIAG / 64; i++) LGk[lane + 64 * i] = dgr[i];
+    };
+    // block b -> LDS parity par: loads first, the probit arithmetic covers their latency
     auto stage = [&](int b, int par) __attribute__((always_inline)) {
-      double st_g[RPG], st_m[RPG], st_G[4], st_Gx[4];
+      double st_g[RPG], st_m[RPG], st_G[4], st_Gx[4], st_xn[RPG];
 #pragma unroll
       for (int r = 0; r < RPG; r++) {
         const size_t off = tbase + (size_t)(16 * b + hg + NG * r) * 16;
         st_g[r] = a.gam[off];
         st_m[r] = a.mu[off];
       }
+      if constexpr (MASK) {
+        const double *gk = gk_block(b);
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        st_G[r] = a.G[(size_t)b * 256 + lane + 64 * r];
-        st_Gx[r] = a.Gx[(size_t)b * 256 + lane + 64 * r];
+        for (int r = 0; r < RPG; r++) {
+          const int jj = hg + NG * r;
+          st_xn[r] = gk[(jj * (jj + 1) / 2 + jj) * 16 + ht];     // X_norm_sq(j,k) = the diagonal of the trait's own block
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          st_G[r] = a.G[(size_t)b * 256 + lane + 64 * r];
+          st_Gx[r] = a.Gx[(size_t)b * 256 + lane + 64 * r];
+        }
       }
-      // (the annealing test sits OUTSIDE the entry loop: a branch per entry would fence the entries off from each other, and
-      // the dependent chains of one probit evaluation -- ~100 operations -- need the other entries to fill the pipeline)
 #pragma unroll
       for (int r = 0; r < RPG; r++) {
         const int j = 16 * b + hg + NG * r, e = lane + 64 * r;
@@ -557,21 +649,55 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           imr0 /= a.sqrt_c;
         }
         const bool valid = kvalid && j < a.p;
-        LA[par][e] = valid ? A : 0.0;
         LB[par][e] = valid ? imr1 - imr0 : 0.0;
         Laa[par][e] = valid ? u + imr0 : 0.0;
+        if constexpr (MASK) {
+          const double s2 = 1.0 / (a.c * (st_xn[r] + sig2_inv_h) * tau_k);     // update_sig2_beta_vb_ with X_norm_sq, R/update_vb.R:45
+          const double ls2 = log(s2);
+          const double cf = a.c * s2 * tau_k;                                  // src/coreLoop.cpp:125
+          LA[par][e] = a.c * ((valid ? A : 0.0) - 0.5 * ls2 + cstna_k);        // :127-129
+          Lcoef[par][e] = cf;
+          LK[par][e] = cf * cf * (a.c * 0.5 / s2);                             // coef^2 c / (2 sig2_beta): x = cA - s^2 K
+          Ls2[par][e] = s2;
+          Lls2[par][e] = ls2;
+        } else {
+          LA[par][e] = valid ? A : 0.0;
+        }
       }
 #pragma unroll
       for (int r = 0; r < RPG; r++) Lm1[par][lane + 64 * r] = st_g[r] * st_m[r];
+      if constexpr (MASK) {
+        // the 16 cross blocks X_b' diag(mis_k) X_{b-1}: 32 KB straight through (global -> registers -> LDS), two chunks in flight
+        const double2 *src = (const double2 *)(gk_block(b) + AQ_GK_DIAG) + lane;
+        double2 *dst = (double2 *)&LGxk[par][0] + lane;
+        double2 c0[8], c1[8];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int e = lane + 64 * r;
-        LG[par][(e >> 4) * 32 + (e & 15)] = st_G[r];
-        LGx[par][e] = st_Gx[r];
+        for (int i = 0; i < 8; i++) c0[i] = src[64 * i];
+#pragma unroll
+        for (int ch = 0; ch < 4; ch += 2) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) c1[i] = src[64 * (8 * (ch + 1) + i)];
+#pragma unroll
+          for (int i = 0; i < 8; i++) dst[64 * (8 * ch + i)] = c0[i];
+          if (ch + 2 < 4) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) c0[i] = src[64 * (8 * (ch + 2) + i)];
+          }
+#pragma unroll
+          for (int i = 0; i < 8; i++) dst[64 * (8 * (ch + 1) + i)] = c1[i];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int e = lane + 64 * r;
+          LG[par][(e >> 4) * 32 + (e & 15)] = st_G[r];
+          LGx[par][e] = st_Gx[r];
+        }
       }
     };
-    // running column sums of this lane's entries (they all belong to trait ht): sum gam, sum m2, sum beta^2, sum Z
-    double cs0 = 0.0, cs1 = 0.0, cs2 = 0.0, cs3 = 0.0;
+    // running column sums of this lane's entries (they all belong to trait ht): sum gam, sum m2, sum beta^2 (MASK: sum
+    // X_norm_sq (m2 - beta^2), R/update_vb.R:152-154), sum Z, and for MASK sum gam log sig2_beta
+    double cs0 = 0.0, cs1 = 0.0, cs2 = 0.0, cs3 = 0.0, cs5 = 0.0;
     auto finalize = [&](int b, int par) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < RPG; r++) {
@@ -588,9 +714,18 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           const double be = gm * mu;
           gb = Laa[par][e] + gm * LB[par][e];       // Z_jk = a + gam b: its row and column sums are all that is needed
           cs0 += gm;
-          cs1 += (mu * mu + sig2b_k) * gm;          // update_m2_beta_, R/update_vb.R:19-31
-          cs2 += be * be;
           cs3 += gb;
+          if constexpr (MASK) {
+            const double s2 = Ls2[par][e];
+            const double m2 = (mu * mu + s2) * gm;                           // update_m2_beta_, R/update_vb.R:19-31
+            const double xn = 1.0 / (a.c * s2 * tau_k) - sig2_inv_h;         // X_norm_sq(j,k) back from sig2_beta_vb(j,k)
+            cs1 += m2;
+            cs2 += xn * (m2 - be * be);
+            cs5 += gm * Lls2[par][e];
+          } else {
+            cs1 += (mu * mu + sig2b_k) * gm;        // update_m2_beta_, R/update_vb.R:19-31
+            cs2 += be * be;
+          }
         }
         gb = aq_row16_sum(gb);                      // over the 16 traits of the tile (one DPP row)
         if ((ht & 15) == 0 && lead) a.rowGB[(size_t)(tile0 + (ht >> 4)) * a.p_pad + j] = gb;
@@ -615,9 +750,11 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           double be = gm * mu;                                  // update_beta_vb_, R/update_vb.R:17
           Ldel[par][e] = be;
           if (kvalid && (16 * b + hj) < a.p) {
+            const double m2 = (mu * mu + sig2b_k) * gm;         // initial m2_beta (q-vector sig2_beta_vb), R/atlasqtl_global_local_core.R:113
             cs0 += gm;
-            cs1 += (mu * mu + sig2b_k) * gm;                    // initial m2_beta, R/atlasqtl_global_local_core.R:113
-            cs2 += be * be;
+            cs1 += m2;
+            if constexpr (MASK) cs2 += gk_block(b)[(hj * (hj + 1) / 2 + hj) * 16 + ht] * (m2 - be * be);
+            else cs2 += be * be;
           }
         }
         signal(6, k + 1);
@@ -625,6 +762,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     } else {
       theta_load(seg_b0);
       stage(seg_b0, seg_b0 & 1);
+      if constexpr (MASK) { diag_load(seg_b0); diag_commit(); signal(12, 1); }
       if (seg_b0 + 1 < seg_b1) theta_load(seg_b0 + 1);
       signal(7, 1);
       for (int b = seg_b0; b < seg_b1; b++) {
@@ -633,15 +771,21 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         // overwritten with block b+1 are the ones it read
         if (b > seg_b0) { wait_ge(6, b - seg_b0); finalize(b - 1, par ^ 1); }
         if (b + 1 < seg_b1) {
+          if constexpr (MASK) diag_load(b + 1);
           stage(b + 1, par ^ 1);
           if (b + 2 < seg_b1) theta_load(b + 2);
           signal(7, b - seg_b0 + 2);
+          if constexpr (MASK) {   // the single LGk buffer is free once the chain of block b is through
+            wait_ge(6, b - seg_b0 + 1);
+            diag_commit();
+            signal(12, b - seg_b0 + 2);
+          }
         }
       }
       wait_ge(6, nblk);
       finalize(seg_b1 - 1, (seg_b1 - 1) & 1);
     }
-    Lred[0][lane] = cs0; Lred[1][lane] = cs1; Lred[2][lane] = cs2; Lred[3][lane] = cs3;   // [row group][trait]
+    Lred[0][lane] = cs0; Lred[1][lane] = cs1; Lred[2][lane] = cs2; Lred[3][lane] = cs3; Lred[5][lane] = cs5;   // [row group][trait]
     __syncthreads();   // matches the matrix waves' barrier before the final sums
   } else {
     // =========================== matrix waves ==============================================
@@ -661,10 +805,11 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     int k2 = tile0 * 16 + tid;
     double r2 = 0.0;
     for (int s = 0; s < NPS * 4; s++) r2 += Lrn[s][tid];
-    double *sm = a.sums + (size_t)seg * 5 * a.q_pad;
+    double *sm = a.sums + (size_t)seg * (MASK ? 6 : 5) * a.q_pad;   // MASK: the six rows of the NA forms (aq_core_sweep_mis.h)
     if (C > 1) a.rnpart[(size_t)part * a.q_pad + k2] = r2;   // added over the parts by aq_k_sum_parts
     else sm[(size_t)4 * a.q_pad + k2] = r2;
-    for (int v = 0; v < 4 && lead; v++) {
+    for (int v = 0; v < 6 && lead; v++) {
+      if (v == 4 || (v == 5 && !MASK)) continue;
       double acc2 = 0.0;
       for (int jj = 0; jj < NG; jj++) acc2 += Lred[v][jj * NTR + tid];
       sm[(size_t)v * a.q_pad + k2] = acc2;

@@ -549,3 +549,56 @@ __global__ void aq_k_sum_parts(const double *__restrict__ rnpart, double *__rest
   for (int c = 0; c < C; c++) s += rnpart[(size_t)c * q_pad + k];
   dst[k] = s;
 }
+
+// ---- per-trait Gram blocks for the masked form of the look-ahead kernel (AqCoreArgs::GK) -------------------------------------
+// For every trait tile and SNP block b, and each of the tile's 16 traits k:
+//     diagonal block  X_b' diag(mis_k) X_b     = X_b'X_b     - Xm_k(b)' Xm_k(b)        lower triangle [i (i + 1) / 2 + j][k]
+//     cross block     X_b' diag(mis_k) X_{b-1} = X_b'X_{b-1} - Xm_k(b)' Xm_k(b-1)      [i][j][k]
+// (Xm_k(b) = the rows of X_b at trait k's missing samples: rank-m_k f64-MFMA corrections from gathered 128-byte row segments,
+// as compute_gk above).  They depend on X and on the missingness pattern only, so they are computed ONCE per handle and kept in
+// HBM -- 50 KB per (tile, block), 98 GB for a C5 trait shard: what 288 GB are for -- instead of being recomputed by every sweep
+// (2 m_k 256 flop per trait and block, a third of the sweep's MFMA work at 5 % missing, and the cross blocks would double it).
+// grid = (ceil(nb / bchunk), ntile), 512 threads; wave w handles the jobs (trait, kind) = w, w + 8, ... of each block.
+__global__ __launch_bounds__(512) void aq_k_gk_blocks(const double *__restrict__ XR, const double *__restrict__ G,
+                                                    const double *__restrict__ Gx, const int *__restrict__ midx,
+                                                    const int *__restrict__ mcnt4, double *__restrict__ GK, int nb, int NR, int Mmax,
+                                                    int bchunk) {
+  extern __shared__ unsigned short aq_gk_lidx[];   // [16][Mmax]
+  __shared__ int Lcnt[16];
+  const int tile = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, col = lane & 15;
+  for (int e = tid; e < 16 * Mmax; e += 512) aq_gk_lidx[e] = (unsigned short)midx[(size_t)tile * 16 * Mmax + e];
+  if (tid < 16) Lcnt[tid] = mcnt4[tile * 16 + tid];
+  __syncthreads();
+  const int b0 = blockIdx.x * bchunk, b1 = min(nb, b0 + bchunk);
+  for (int b = b0; b < b1; b++) {
+    double *out = GK + ((size_t)tile * nb + b) * AQ_GK_STRIDE;
+    const double *xr = XR + (size_t)b * NR * 16 + col;
+    const double *xp = XR + (size_t)(b > 0 ? b - 1 : 0) * NR * 16 + col;
+    for (int job = w; job < 32; job += 8) {
+      const int k = job & 15, cross = job >> 4;
+      aq_d4 acc = (aq_d4){0, 0, 0, 0};
+      const int n4 = (cross && b == 0) ? 0 : Lcnt[k];
+      const unsigned short *ix = aq_gk_lidx + k * Mmax + g;
+      for (int t = 0; t < n4; t += 4) {   // lists are padded to whole groups of 16 samples (index n_pad = an all-zero row)
+        const int i0 = ix[4 * t], i1 = ix[4 * t + 4], i2 = ix[4 * t + 8], i3 = ix[4 * t + 12];
+        const double a0 = xr[(size_t)i0 * 16], a1 = xr[(size_t)i1 * 16], a2 = xr[(size_t)i2 * 16], a3 = xr[(size_t)i3 * 16];
+        if (cross) {
+          const double c0 = xp[(size_t)i0 * 16], c1 = xp[(size_t)i1 * 16], c2 = xp[(size_t)i2 * 16], c3 = xp[(size_t)i3 * 16];
+          acc = aq_mfma(a0, c0, acc); acc = aq_mfma(a1, c1, acc); acc = aq_mfma(a2, c2, acc); acc = aq_mfma(a3, c3, acc);
+        } else {
+          acc = aq_mfma(a0, a0, acc); acc = aq_mfma(a1, a1, acc); acc = aq_mfma(a2, a2, acc); acc = aq_mfma(a3, a3, acc);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = 4 * r + g, j = col;            // D layout: row = 4 reg + (lane >> 4), column = lane & 15
+        if (cross) {
+          const double base = b > 0 ? Gx[(size_t)b * 256 + i * 16 + j] : 0.0;
+          out[AQ_GK_DIAG + (i * 16 + j) * 16 + k] = base - acc[r];
+        } else if (i >= j) {
+          out[(i * (i + 1) / 2 + j) * 16 + k] = G[(size_t)b * 256 + i * 16 + j] - acc[r];
+        }
+      }
+    }
+  }
+}

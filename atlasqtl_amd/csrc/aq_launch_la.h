@@ -9,3 +9,5 @@
 // no instantiation for (NT, NT2): NT in 1..11, NT2 in {NT, NT - 1}.
 int aq_la_launch_tt1(int NT, int NT2, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a);
 int aq_la_launch_tt2(int NT, int NT2, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a);
+// the MASK instances (Y with missing values; one trait tile per workgroup): aq_launch_la1m.hip
+int aq_la_launch_mask(int NT, int NT2, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a);

@@ -145,6 +145,9 @@ struct aq_vb {
   double *Aarr = nullptr, *Barr = nullptr, *colApart = nullptr;
   bool use_la = false;   // look-ahead kernel (aq_core_sweep_la.h)
   int laC = 1;           // look-ahead kernel: workgroups (sample parts) per trait group, n > 1056
+  int max_missing = 0;   // most missing samples of one trait
+  bool la_mask = false;  // look-ahead kernel, MASK instances: Y with missing values, per-trait Gram blocks precomputed into GK
+  double *GK = nullptr;  // [ntile][nb][AQ_GK_STRIDE]
   int TT = 1;            // look-ahead kernel: 16-trait tiles per workgroup (2 when there are enough tiles to fill the chip)
   int stagger = 0;       // look-ahead kernel: tile at which a matrix wave releases its SIMD partner into the phase (0 = off)
   int NT2 = 0;           // look-ahead kernel: tiles of matrix waves 4,5,6 (NT: waves 0,1,2)
@@ -197,7 +200,7 @@ struct aq_vb {
 static void aq_free_all(aq_vb *s) {
   if (!s) return;
   hipSetDevice(s->device);
-  void *ptrs[] = {s->Pbuf, s->rnpart, s->pflag, s->XR, s->midx, s->mcnt4, s->Xcm, s->mis, s->XN, s->XA, s->XU, s->G, s->Gx, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
+  void *ptrs[] = {s->GK, s->Pbuf, s->rnpart, s->pflag, s->XR, s->midx, s->mcnt4, s->Xcm, s->mis, s->XN, s->XA, s->XU, s->G, s->Gx, s->R, s->gam, s->mu, s->theta, s->sig2_theta, s->L, s->lam2_inv, s->Q, s->ppart,
                   s->eta_h, s->kappa_h, s->n0, s->nobs, s->zeta, s->tau, s->sig2b, s->log_tau, s->eta_vb, s->kappa_vb,
                   s->coef, s->inv2s, s->cst, s->sums, s->rowA, s->rowGB, s->Aarr, s->Barr, s->colApart, s->Hpart, s->sc};
   for (void *ptr : ptrs)
@@ -308,6 +311,8 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     const unsigned nwg = (unsigned)(s->ntile / s->TT);
     a.done = s->done; a.errflag = s->errflag; a.stagger = s->stagger;
     a.C = s->laC; a.Pbuf = s->Pbuf; a.pflag = s->pflag; a.rnpart = s->rnpart;
+    a.mis = s->mis; a.GK = s->GK; a.tau = s->tau; a.log_tau = s->log_tau;
+    a.sig2_inv_p = &s->sc->sig2_inv; a.log_sig2_inv_p = &s->sc->log_sig2_inv;
     if (s->laC > 1) AQ_HIP(hipMemsetAsync(s->pflag, 0, (size_t)s->ntile * s->laC * sizeof(int), 0));
     a.dbg = nullptr;
     static long long *dbg_buf = nullptr;   // AQ_DIAG_DUMP=<file> with a -DAQ_DIAG_TIME build: per-role wait / total cycles of sweep 15
@@ -323,10 +328,13 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     if (chained) AQ_HIP(hipMemsetAsync(s->done, 0, (size_t)s->ntile * sizeof(int), 0));
     // chained-segment launch: chain * nwg workgroups, workgroup s*nwg + k = SNP segment s of trait-tile group k
     const unsigned grid = chained ? (unsigned)((long long)s->chain * nwg) : nwg * (unsigned)s->laC;
-    int lrc = s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
+    int lrc = s->la_mask ? aq_la_launch_mask(s->NT, s->NT2, chained, grid, 0, a)
+              : s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
     if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
-    if (chained)
-      hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
+    if (chained) {
+      if (s->la_mask) hipLaunchKernelGGL(aq_k_combine_segment_sums6, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
+      else hipLaunchKernelGGL(aq_k_combine_segment_sums, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
+    }
     if (s->laC > 1)
       hipLaunchKernelGGL(aq_k_sum_parts, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->rnpart, s->sums + (size_t)4 * s->q_pad, s->laC, s->q_pad);
     if (a.dbg && s->it == 15) {
@@ -442,11 +450,26 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         int m = 0;
         for (int i = 0; i < pr->n; i++) m += !(Yh[(size_t)i + (size_t)pr->n * k] == Yh[(size_t)i + (size_t)pr->n * k]);
         if (m > max_missing) max_missing = m;
+        s->max_missing = max_missing;
       }
     }
     // the masked MFMA kernel also serves complete Y beyond the look-ahead kernel's n (all-ones mask, empty lists)
-    const bool la_split_ok = !has_missing && pr->n > 1056 && pr->n <= 8 * 16 * 105 && !(ek && atoi(ek) >= 2);   // complete Y, large n
-    if ((has_missing || (pr->n > 1056 && !la_split_ok)) && pr->n <= 16384 && max_missing <= AQ_MIS_MMAX && !(ek && atoi(ek) == 2)) {
+    // Y with missing values: the look-ahead kernel's MASK instances when the per-trait Gram blocks (50 KB per trait tile and
+    // SNP block, computed once) fit next to the rest of the state in HBM; else the masked two-barrier kernel (AQ_KERNEL=3
+    // forces that one), which recomputes them every sweep.  Complete Y beyond n = 1056: look-ahead kernel with a sample split.
+    const bool n_la_ok = pr->n <= 8 * 16 * 105;
+    bool la_mask_ok = has_missing && n_la_ok && max_missing <= AQ_MIS_MMAX && !(ek && atoi(ek) >= 2);
+    if (la_mask_ok) {
+      size_t free_b = 0, tot_b = 0;
+      const size_t ntile_ = (size_t)(pr->q + 15) / 16, nb_ = (size_t)(pr->p + 15) / 16;
+      const size_t gk_b = ntile_ * nb_ * AQ_GK_STRIDE * sizeof(double);
+      const size_t rest_b = 2 * ntile_ * nb_ * 256 * sizeof(double) + 3 * (size_t)(pr->n + 64) * nb_ * 16 * sizeof(double) * 2 +
+                            3 * ntile_ * (size_t)(pr->n + 64) * 16 * sizeof(double);
+      if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess || (double)(gk_b + rest_b) * 1.05 > (double)free_b) la_mask_ok = false;
+      if (const char *e = getenv("AQ_GK_MAX_GB")) if ((double)gk_b > atof(e) * 1e9) la_mask_ok = false;   // test hook: force the fallback
+    }
+    const bool la_split_ok = !has_missing && pr->n > 1056 && n_la_ok && !(ek && atoi(ek) >= 2);   // complete Y, large n
+    if (!la_mask_ok && (has_missing || (pr->n > 1056 && !la_split_ok)) && pr->n <= 16384 && max_missing <= AQ_MIS_MMAX && !(ek && atoi(ek) == 2)) {
       s->use_mis = true;
       s->NW = 8;
       // n_pad = 128 NT C: C workgroups per trait tile, NT in {1,2,4,8,16} residual tiles per wave.  Model of a sweep:
@@ -472,7 +495,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       }
       s->Mmax = (max_missing + 15) / 16 * 16;
       if (s->Mmax < 16) s->Mmax = 16;
-    } else if (has_missing || (ek && atoi(ek) == 2) || (pr->n > 1056 && !la_split_ok)) {
+    } else if ((has_missing && !la_mask_ok) || (ek && atoi(ek) == 2) || (pr->n > 1056 && !la_split_ok && !la_mask_ok)) {
       // generic kernel geometry: n_pad = 64 * NE * WPT samples, WPT waves (and workgroups) per trait (tile)
       s->use_tw = true;
       s->WPT = pr->n <= 2048 ? 1 : pr->n <= 5120 ? 2 : 4;
@@ -484,6 +507,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       // 6 matrix waves (NT tiles on waves 0-2, NT2 = NT or NT - 1 on waves 4-6: NT + NT2 per SIMD) + the recurrence wave,
       // which owns aq_la_nt3(NT, TT) tiles of its own when two trait tiles share a workgroup
       s->use_la = true;
+      s->la_mask = la_mask_ok;
       const int ntiles = (pr->n + 15) / 16;
       s->NW = 6;
       // two trait tiles per workgroup once that still gives every CU a workgroup (C3: 625 tiles -> 313 workgroups of 32
@@ -491,6 +515,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       // q is then padded to a multiple of 32 (the extra tile is all padding: zero residual, masked sums).
       s->TT = ((s->ntile + 1) / 2 >= s->ncu) ? 2 : 1;
       if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 2 ? 2 : 1;
+      if (s->la_mask) s->TT = 1;   // 16 per-trait Gram blocks per trait tile in LDS: one tile per workgroup
       if (s->TT == 2) {
         s->q_pad = (pr->q + 31) / 32 * 32;
         s->ntile = s->q_pad / 16;
@@ -587,7 +612,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   s->scheme = pr->scheme; s->df = pr->scheme == 1 ? 1 : (pr->df == 0 ? 1 : pr->df);
   std::memcpy(s->anneal, pr->anneal, sizeof(s->anneal));
   s->tol = pr->tol; s->maxit = pr->maxit; s->thinned = pr->thinned_elbo_eval != 0; s->debug = pr->debug != 0;
-  s->has_missing = has_missing || s->use_mis;   // the masked kernel produces the NA forms of the column sums (identical for complete Y)
+  s->has_missing = has_missing || s->use_mis || s->la_mask;   // the masked kernel produces the NA forms of the column sums (identical for complete Y)
 
   auto fail = [&](int code) { aq_free_all(s); return code; };
 #define AQ_TRYF(x) do { int rc2_ = (x); if (rc2_ != AQ_OK) return fail(rc2_); } while (0)
@@ -603,14 +628,21 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     AQ_TRYF(aq_dalloc(&s->mis, (size_t)s->ntile * s->n_pad * 16));
     AQ_TRYF(aq_dalloc(&s->XN, (size_t)s->ntile * s->p_pad * 16));
   }
-  if (s->use_mis) {
+  if (s->la_mask) {
+    s->Mmax = (s->max_missing + 15) / 16 * 16;
+    if (s->Mmax < 16) s->Mmax = 16;
+    s->NR = s->n_pad + 8;
+  }
+  if (s->use_mis || s->la_mask) {
     AQ_TRYF(aq_dalloc(&s->mis, (size_t)s->ntile * s->n_pad * 16));
     AQ_TRYF(aq_dalloc(&s->XR, (size_t)s->nb * s->NR * 16));
     AQ_TRYF(aq_dalloc(&s->midx, (size_t)s->ntile * 16 * s->Mmax));
     AQ_TRYF(aq_dalloc(&s->mcnt4, (size_t)s->ntile * 16));
-    AQ_TRYF(aq_dalloc(&s->Pbuf, (size_t)s->ntile * 2 * s->misC * 256));
-    AQ_TRYF(aq_dalloc(&s->pflag, (size_t)s->ntile * s->misC));
-    AQ_TRYF(aq_dalloc(&s->rnpart, (size_t)s->misC * s->q_pad));
+    if (s->use_mis) {
+      AQ_TRYF(aq_dalloc(&s->Pbuf, (size_t)s->ntile * 2 * s->misC * 256));
+      AQ_TRYF(aq_dalloc(&s->pflag, (size_t)s->ntile * s->misC));
+      AQ_TRYF(aq_dalloc(&s->rnpart, (size_t)s->misC * s->q_pad));
+    }
     // lists of missing samples per trait, padded to groups of 16 with the all-zero row n_pad of XR
     std::vector<int> idx((size_t)s->ntile * 16 * s->Mmax, s->n_pad), cnt((size_t)s->ntile * 16, 0);
     for (int k = 0; k < s->q; k++) {
@@ -677,12 +709,24 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       hipLaunchKernelGGL(aq_k_build_x_layouts, dim3((unsigned)((xelems + 255) / 256)), dim3(256), 0, 0, Xd, s->XA, s->XU,
                          s->n, s->p, s->nb, NTT, s->dmode);
       hipLaunchKernelGGL(aq_k_gram_blocks, dim3(s->nb), dim3(256), 0, 0, Xd, s->G, s->Gx, s->n, s->p);
-      if (s->use_mis) {
+      if (s->use_mis || s->la_mask) {
         size_t tot = (size_t)s->nb * s->NR * 16;
         hipLaunchKernelGGL(aq_k_build_xr, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, Xd, s->XR, s->n, s->p, s->nb, s->NR);
       }
       AQ_HIPF(hipDeviceSynchronize());
       if (own_x) AQ_HIPF(hipFree(Xd));
+      if (s->la_mask) {
+        // the traits' own Gram blocks, once per handle (aq_core_sweep_mis.h::aq_k_gk_blocks); the row panels are not needed after
+        AQ_TRYF(aq_dalloc(&s->GK, (size_t)s->ntile * s->nb * AQ_GK_STRIDE));
+        const int bchunk = 32;
+        const size_t lds = (size_t)16 * s->Mmax * sizeof(unsigned short);
+        hipLaunchKernelGGL(aq_k_gk_blocks, dim3((s->nb + bchunk - 1) / bchunk, s->ntile), dim3(512), lds, 0, s->XR, s->G, s->Gx, s->midx, s->mcnt4,
+                           s->GK, s->nb, s->NR, s->Mmax, bchunk);
+        AQ_HIPF(hipGetLastError());
+        AQ_HIPF(hipDeviceSynchronize());
+        AQ_HIPF(hipFree(s->XR));
+        s->XR = nullptr;
+      }
     }
   }
   {
@@ -693,7 +737,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
     hipLaunchKernelGGL(aq_k_tile_from_colmajor, dim3((s->n_pad + 63) / 64, s->ntile), dim3(256), 0, 0, stage, s->R,
                        s->n, s->q, s->n_pad, 1);
     AQ_HIPF(hipDeviceSynchronize());
-    if (s->use_tw || s->use_mis) {   // mis_pat <- ifelse(is.na(Y), 0, 1), R/atlasqtl_global_local_core.R:21
+    if (s->use_tw || s->use_mis || s->la_mask) {   // mis_pat <- ifelse(is.na(Y), 0, 1), R/atlasqtl_global_local_core.R:21
       std::vector<double> mk(nq);
       for (size_t i = 0; i < nq; i++) mk[i] = (Yh[i] == Yh[i]) ? 1.0 : 0.0;
       AQ_HIPF(hipMemcpy(stage, mk.data(), nq * sizeof(double), hipMemcpyHostToDevice));

@@ -30,7 +30,7 @@ def _run(X, Y, lh, li, q, sweeps, **env):
     return st, tr, rs, nb
 
 
-def test_c2_two_kernels_agree_and_elbo_is_monotone():
+def test_c2_two_kernels_agree_and_elbo_is_monotone(monkeypatch):
     """C2 = BASELINE.json configs[1]: n = 1000, p = 5000, q = 1000, horseshoe, annealing (1, 2, 10)."""
     n, p, q, sweeps = 1000, 5000, 1000, 40
     X, Y, lh, li = _bench_problem(n, p, q)
@@ -39,8 +39,13 @@ def test_c2_two_kernels_agree_and_elbo_is_monotone():
     its, lbs = tr_a
     assert len(lbs) >= 25 and np.all(np.diff(lbs) > -1e-6 * np.abs(lbs[0]) * 1e-6)      # monotone (debug=True also enforces it)
     X2, Y2, lh2, li2 = _bench_problem(n, p, q, na_entry=True)
+    st_c, tr_c, rs_c, nb_c = _run(X2, Y2, lh2, li2, q, sweeps)      # look-ahead kernel, MASK instances (per-trait Gram blocks from HBM)
+    assert st_c["core_kernel"] == 0
+    monkeypatch.setenv("AQ_KERNEL", "3")                            # the two-barrier masked kernel: an independent statement of the NA forms
     st_b, tr_b, rs_b, nb_b = _run(X2, Y2, lh2, li2, q, sweeps)
     assert st_b["core_kernel"] == 3
+    np.testing.assert_allclose(tr_c[1], tr_b[1], rtol=1e-10)
+    assert nb_c == nb_b
     # one entry of 10^6 is missing: the two runs differ by that entry's information only (~1e-6 relative on the ELBO)
     np.testing.assert_allclose(tr_b[1], tr_a[1], rtol=2e-5)
     assert abs(nb_a - nb_b) <= max(2, nb_a // 100)

@@ -138,15 +138,19 @@ def test_generic_kernel_split_traits_matches_oracle(shape, na, wpt, monkeypatch)
     _check_against_oracle(make_problem(n, p, q, p_act=8, prob_assoc=0.3, na_frac=na), q)
 
 
-@pytest.mark.parametrize("shape,na,kernel", [((2500, 40, 20), 0.05, 3), ((5000, 24, 17), 0.05, 3), ((5200, 20, 9), 0.0, 0),
-                                             ((2500, 40, 20), 0.0, 0), ((1100, 50, 33), 0.0, 0)])
-def test_large_n_matches_oracle(shape, na, kernel):
+@pytest.mark.parametrize("force_old", [False, True])
+@pytest.mark.parametrize("shape,na", [((2500, 40, 20), 0.05), ((5000, 24, 17), 0.05), ((5200, 20, 9), 0.0), ((2500, 40, 20), 0.0),
+                                      ((1100, 50, 33), 0.0), ((1100, 50, 33), 0.1)])
+def test_large_n_matches_oracle(shape, na, force_old, monkeypatch):
     """n beyond one workgroup's registers (C5 has n = 5000 and a missingness mask): the sample axis split over cooperating
-    workgroups per trait tile -- the masked MFMA kernel with missing values, the look-ahead kernel (core_kernel 0: partial S'
-    exchanged by the recurrence waves, redundant chains) for complete Y."""
+    workgroups per trait tile.  Default: the look-ahead kernel (core_kernel 0: partial S' exchanged by the recurrence waves,
+    redundant chains; MASK instances with per-trait Gram blocks from HBM when Y has missing values); AQ_KERNEL=3: the
+    two-barrier masked kernel, which stays the fallback when those blocks do not fit the memory."""
     from tests.util import make_problem
+    if force_old:
+        monkeypatch.setenv("AQ_KERNEL", "3")
     n, p, q = shape
-    _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q, kernel=kernel)
+    _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q, kernel=3 if force_old else 0)
 
 
 @pytest.mark.parametrize("C", [2, 3, 5, 8])
@@ -175,6 +179,7 @@ def test_masked_kernel_sample_split_matches_oracle(shape, na, C, monkeypatch):
     """The cross-workgroup exchange of partial S (release/acquire flags, redundant recursion) forced at small n."""
     from tests.util import make_problem
     monkeypatch.setenv("AQ_MIS_C", str(C))
+    monkeypatch.setenv("AQ_KERNEL", "3")
     n, p, q = shape
     prob = make_problem(n, p, q, p_act=8, prob_assoc=0.3, na_frac=na)
     if na == 0.0:   # complete Y reaches the masked kernel only beyond the look-ahead kernel's n; poke one NaN in
@@ -184,12 +189,34 @@ def test_masked_kernel_sample_split_matches_oracle(shape, na, C, monkeypatch):
 
 @pytest.mark.parametrize("shape,na", [((70, 17, 1), 0.1), ((128, 40, 16), 0.3), ((200, 90, 33), 0.08), ((300, 130, 49), 0.02),
                                       ((600, 50, 20), 0.05), ((1100, 40, 18), 0.05), ((2048, 33, 17), 0.03)])
-def test_masked_mfma_kernel_matches_oracle(shape, na):
-    """Missing values in Y on the blocked f64-MFMA kernel (aq_core_sweep_mis.h, core_kernel == 3): every residual-tile
-    geometry NT = 1, 2, 4, 8, 16, ragged p and q, one trait, 30 % missing."""
+def test_masked_mfma_kernel_matches_oracle(shape, na, monkeypatch):
+    """Missing values in Y on the two-barrier masked f64-MFMA kernel (aq_core_sweep_mis.h, core_kernel == 3, forced with
+    AQ_KERNEL=3: the fallback of the look-ahead MASK path): every residual-tile geometry NT = 1, 2, 4, 8, 16, ragged p and q,
+    one trait, 30 % missing."""
     from tests.util import make_problem
+    monkeypatch.setenv("AQ_KERNEL", "3")
     n, p, q = shape
     _check_against_oracle(make_problem(n, p, q, p_act=min(6, p // 3), prob_assoc=1.0 if q <= 20 else 0.3, na_frac=na), q, kernel=3)
+
+
+@pytest.mark.parametrize("env", [{}, {"AQ_CHAIN": "3"}, {"AQ_LA_C": "2"}, {"AQ_LA_C": "5"}])
+@pytest.mark.parametrize("shape,na", [((70, 17, 1), 0.1), ((128, 40, 16), 0.3), ((200, 90, 33), 0.08), ((300, 130, 49), 0.02),
+                                      ((600, 50, 20), 0.05), ((1000, 64, 18), 0.05)])
+def test_look_ahead_mask_kernel_matches_oracle(shape, na, env, monkeypatch):
+    """Missing values in Y on the look-ahead kernel (MASK instances, core_kernel == 0): the residual re-masked after every
+    update, the traits' own diagonal and cross Gram blocks precomputed into HBM and staged through LDS, per-entry
+    sig2_beta_vb, the NA forms of the column sums; plain, with chained SNP segments and with the sample split."""
+    from tests.util import make_problem
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, p, q = shape
+    _check_against_oracle(make_problem(n, p, q, p_act=min(6, p // 3), prob_assoc=1.0 if q <= 20 else 0.3, na_frac=na), q, kernel=0)
+
+
+def test_mask_path_falls_back_when_the_gram_blocks_do_not_fit(monkeypatch):
+    from tests.util import make_problem
+    monkeypatch.setenv("AQ_GK_MAX_GB", "0.000001")
+    _check_against_oracle(make_problem(200, 90, 33, p_act=6, prob_assoc=0.3, na_frac=0.08), 33, kernel=3)
 
 
 def test_missing_beyond_index_list_capacity_falls_back_to_generic():
@@ -207,5 +234,6 @@ def test_masked_kernel_chained_segments_match_oracle(shape, na, chain, monkeypat
     forced at small size with AQ_CHAIN."""
     from tests.util import make_problem
     monkeypatch.setenv("AQ_CHAIN", str(chain))
+    monkeypatch.setenv("AQ_KERNEL", "3")
     n, p, q = shape
     _check_against_oracle(make_problem(n, p, q, p_act=8, prob_assoc=0.3, na_frac=na), q, kernel=3)
