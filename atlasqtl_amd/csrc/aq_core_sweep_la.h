@@ -56,6 +56,13 @@ __device__ __forceinline__ double aq_row16_sum(double v) {
   return v;
 }
 
+// One LDS-DMA transfer (global_load_lds_dwordx4): 64 lanes x 16 B from per-lane global addresses to lds_base + 16 lane, with
+// no VGPR destination; completion is counted in vmcnt.  lds_base must be wave-uniform.
+__device__ __forceinline__ void aq_glds16(const void *gsrc_lane, void *lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                   (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The residual tiles live in
 // registers only while every index into them is a constant expression.
 template <int... Is, class F>
@@ -597,39 +604,53 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #pragma unroll
       for (int r = 0; r < RPG; r++) th[r] = a.theta[16 * b + hg + NG * r];
     };
-    // block b -> LDS parity par: loads first, the probit arithmetic covers their latency
     // MASK: per-trait constants of the NA forms (src/coreLoop.cpp:108, R/update_vb.R:45) and this block's slice of GK
     const double tau_k = MASK ? a.tau[ktrait] : 1.0;
     const double sig2_inv_h = MASK ? *a.sig2_inv_p : 0.0;
     const double cstna_k = MASK ? -(a.log_tau[ktrait] + *a.log_sig2_inv_p) / 2 : 0.0;
     auto gk_block = [&](int b) __attribute__((always_inline)) { return a.GK + ((size_t)tile0 * a.nb + b) * AQ_GK_STRIDE; };
-    double dgr[MASK ? AQ_GK_DIAG / 64 : 1];   // diagonal blocks of the block being staged, on their way to the single LGk buffer
-    auto diag_load = [&](int b) __attribute__((always_inline)) {
+    // The Gram blocks go global -> LDS by LDS-DMA: no registers, and the whole 50 KB of a block is in flight at once (through
+    // registers one wave cannot keep enough loads outstanding: the staging alone took 4x the phase).  hipcc drains vmcnt(0) at
+    // the first use of an ordinary load's result while a DMA is pending, so every ordinary load of an iteration is consumed
+    // before the DMAs are issued (the helper's own loads run one block ahead, see `pre_load`).
+    auto cross_dma = [&](int b, int par) __attribute__((always_inline)) {   // 16 cross blocks, 32 KB -> LGxk[par]
+      const char *src = (const char *)(gk_block(b) + AQ_GK_DIAG) + lane * 16;
+#pragma unroll
+      for (int i = 0; i < 32; i++) aq_glds16(src + 1024 * i, &LGxk[par][128 * i]);
+    };
+    auto diag_dma = [&](int b) __attribute__((always_inline)) {             // 16 diagonal blocks (lower triangles), 17 KB -> LGk
+      const char *src = (const char *)gk_block(b) + lane * 16;
+#pragma unroll
+      for (int i = 0; i < AQ_GK_DIAG / 128; i++) aq_glds16(src + 1024 * i, &LGk[128 * i]);
+    };
+    // block b -> LDS parity par.  Complete Y: loads first, the probit arithmetic covers their latency.  MASK: gam, mu and the
+    // diagonal X_norm_sq(j,k) of block b were requested by pre_load(b) an iteration earlier.
+    double pl_g[MASK ? RPG : 1], pl_m[MASK ? RPG : 1], pl_xn[MASK ? RPG : 1];
+    auto pre_load = [&](int b) __attribute__((always_inline)) {
       const double *gk = gk_block(b);
-#pragma unroll
-      for (int i = 0; i < AQ_GK_DIAG / 64; i++) dgr[i] = gk[lane + 64 * i];
-    };
-    auto diag_commit = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < AQ_GK_DIAG / 64; i++) LGk[lane + 64 * i] = dgr[i];
-    };
-    // block b -> LDS parity par: loads first, the probit arithmetic covers their latency
-    auto stage = [&](int b, int par) __attribute__((always_inline)) {
-      double st_g[RPG], st_m[RPG], st_G[4], st_Gx[4], st_xn[RPG];
 #pragma unroll
       for (int r = 0; r < RPG; r++) {
         const size_t off = tbase + (size_t)(16 * b + hg + NG * r) * 16;
-        st_g[r] = a.gam[off];
-        st_m[r] = a.mu[off];
+        const int jj = hg + NG * r;
+        pl_g[r] = a.gam[off];
+        pl_m[r] = a.mu[off];
+        pl_xn[r] = gk[(jj * (jj + 1) / 2 + jj) * 16 + ht];     // X_norm_sq(j,k) = the diagonal of the trait's own block
       }
+    };
+    auto stage = [&](int b, int par) __attribute__((always_inline)) {
+      double st_g[RPG], st_m[RPG], st_G[4], st_Gx[4], st_xn[RPG];
       if constexpr (MASK) {
-        const double *gk = gk_block(b);
+#pragma unroll
+        for (int r = 0; r < RPG; r++) { st_g[r] = pl_g[r]; st_m[r] = pl_m[r]; st_xn[r] = pl_xn[r]; }
+        asm volatile("" : "+v"(st_xn[0]) : : "memory");   // (the values are in registers by now: nothing of them is waited for below)
+        cross_dma(b, par);
+      } else {
 #pragma unroll
         for (int r = 0; r < RPG; r++) {
-          const int jj = hg + NG * r;
-          st_xn[r] = gk[(jj * (jj + 1) / 2 + jj) * 16 + ht];     // X_norm_sq(j,k) = the diagonal of the trait's own block
+          const size_t off = tbase + (size_t)(16 * b + hg + NG * r) * 16;
+          st_g[r] = a.gam[off];
+          st_m[r] = a.mu[off];
         }
-      } else {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           st_G[r] = a.G[(size_t)b * 256 + lane + 64 * r];
@@ -667,25 +688,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #pragma unroll
       for (int r = 0; r < RPG; r++) Lm1[par][lane + 64 * r] = st_g[r] * st_m[r];
       if constexpr (MASK) {
-        // the 16 cross blocks X_b' diag(mis_k) X_{b-1}: 32 KB straight through (global -> registers -> LDS), two chunks in flight
-        const double2 *src = (const double2 *)(gk_block(b) + AQ_GK_DIAG) + lane;
-        double2 *dst = (double2 *)&LGxk[par][0] + lane;
-        double2 c0[8], c1[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) c0[i] = src[64 * i];
-#pragma unroll
-        for (int ch = 0; ch < 4; ch += 2) {
-#pragma unroll
-          for (int i = 0; i < 8; i++) c1[i] = src[64 * (8 * (ch + 1) + i)];
-#pragma unroll
-          for (int i = 0; i < 8; i++) dst[64 * (8 * ch + i)] = c0[i];
-          if (ch + 2 < 4) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) c0[i] = src[64 * (8 * (ch + 2) + i)];
-          }
-#pragma unroll
-          for (int i = 0; i < 8; i++) dst[64 * (8 * (ch + 1) + i)] = c1[i];
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the cross blocks have landed in LGxk[par]
       } else {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -761,8 +764,14 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       }
     } else {
       theta_load(seg_b0);
+      if constexpr (MASK) pre_load(seg_b0);
       stage(seg_b0, seg_b0 & 1);
-      if constexpr (MASK) { diag_load(seg_b0); diag_commit(); signal(12, 1); }
+      if constexpr (MASK) {
+        diag_dma(seg_b0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        signal(12, 1);
+        if (seg_b0 + 1 < seg_b1) pre_load(seg_b0 + 1);
+      }
       if (seg_b0 + 1 < seg_b1) theta_load(seg_b0 + 1);
       signal(7, 1);
       for (int b = seg_b0; b < seg_b1; b++) {
@@ -771,15 +780,16 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         // overwritten with block b+1 are the ones it read
         if (b > seg_b0) { wait_ge(6, b - seg_b0); finalize(b - 1, par ^ 1); }
         if (b + 1 < seg_b1) {
-          if constexpr (MASK) diag_load(b + 1);
           stage(b + 1, par ^ 1);
-          if (b + 2 < seg_b1) theta_load(b + 2);
           signal(7, b - seg_b0 + 2);
           if constexpr (MASK) {   // the single LGk buffer is free once the chain of block b is through
             wait_ge(6, b - seg_b0 + 1);
-            diag_commit();
+            diag_dma(b + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             signal(12, b - seg_b0 + 2);
+            if (b + 2 < seg_b1) pre_load(b + 2);     // ordinary loads last: consumed an iteration later
           }
+          if (b + 2 < seg_b1) theta_load(b + 2);
         }
       }
       wait_ge(6, nblk);

@@ -271,7 +271,8 @@ def test_sharded_core_function_with_device_init_reproduces_single_gpu(tmp_path):
     np.testing.assert_allclose(np.concatenate([r0["gam"], r1["gam"]], axis=1), one["gam_vb"], atol=1e-10)
 
 
-@pytest.mark.parametrize("env", [{"AQ_MIS_C": "3"}, {"AQ_CHAIN": "4"}])
+@pytest.mark.parametrize("env", [{"AQ_MIS_C": "3", "AQ_KERNEL": "3"}, {"AQ_CHAIN": "4"}, {"AQ_LA_C": "2"},
+                                 {"AQ_LA_C": "2", "NA": "1"}])
 def test_expired_in_kernel_wait_is_reported_everywhere(env, monkeypatch):
     """A bounded wait that expires inside a sweep kernel (sample split: a partner's partial S; chained segments: the
     previous segment's residual) raises a device flag: results are invalid.  The flag is forced through the test hook;
@@ -281,11 +282,11 @@ def test_expired_in_kernel_wait_is_reported_everywhere(env, monkeypatch):
     from tests.util import make_problem
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    na = 0.04 if "AQ_MIS_C" in env else 0.0
+    na = 0.04 if ("AQ_MIS_C" in env or "NA" in env) else 0.0
     prob = make_problem(300, 130, 49, p_act=8, prob_assoc=0.3, na_frac=na)
     run = _vbrun(prob)
     run.run_sweeps(3)
-    assert run.status()["core_kernel"] == (3 if na else 0)
+    assert run.status()["core_kernel"] == (3 if "AQ_KERNEL" in env else 0)
     assert lib().aq_vb_debug_raise_errflag(run.h) == 0
     for call in (run.status, run.get_state, run.result, lambda: run.run_sweeps(1)):
         with pytest.raises(AtlasqtlHipError, match=r"\[2\].*bounded wait"):
