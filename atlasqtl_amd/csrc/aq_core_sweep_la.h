@@ -167,11 +167,12 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   __shared__ double Laa[2][ENT];       // intercept a of Z (Z = a + gam b, R/update_vb.R:217-234)
   __shared__ double LG[MASK ? 1 : 2][MASK ? 1 : 512];    // X_b'X_b as [16][32], upper 16 columns zero        (complete Y)
   __shared__ double LGx[MASK ? 1 : 2][MASK ? 1 : 256];   // X_b'X_{b-1}  [j][i]                              (complete Y)
-  // MASK: the traits' own blocks.  Diagonal block: lower triangle [i (i + 1) / 2 + j][trait], ONE buffer (the helper refills it
-  // between two chains, counter Fl[12]); cross block [j][i][trait], by block parity.  Per-entry constants of the chain.
-  __shared__ double LGk[MASK ? AQ_GK_DIAG : 1];
-  __shared__ double LGxk[MASK ? 2 : 1][MASK ? 4096 : 1];
-  __shared__ double Lcoef[2][MASK ? ENT : 1], LK[2][MASK ? ENT : 1], Ls2[2][MASK ? ENT : 1], Lls2[2][MASK ? ENT : 1];
+  // MASK: the traits' own blocks, written by LDS-DMA.  Diagonal block: lower triangle [i (i + 1) / 2 + j][trait], by block
+  // parity; cross block [j][i][trait], ONE buffer (released by the recurrence wave through Fl[13] as soon as the correction
+  // at the start of a chain has read it).  Per-entry constants of the chain.
+  __shared__ double LGk2[MASK ? 2 : 1][MASK ? AQ_GK_DIAG : 1];
+  __shared__ double LGxk[MASK ? 4096 : 1];
+  __shared__ double Lcoef[2][MASK ? ENT : 1], LK[2][MASK ? ENT : 1], Ls2[2][MASK ? ENT : 1], Lls2[2][MASK ? ENT : 1], Lxn[2][MASK ? ENT : 1];
   __shared__ double Lgam[2][ENT], Lmu[2][ENT], Ldel[2][ENT];
   __shared__ double Lred[6][64];       // the helper lanes' column sums [row group][trait], added up per trait at the end
   __shared__ double Lrn[NPS * 4][NTR];
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   // partial S' matrix wave m has written, Fl[6] = blocks the recurrence wave has finished, Fl[7] = blocks the helper
   // wave has staged, Fl[8..10] = phases that matrix wave 0..2 has carried past its stagger tile (its SIMD partner 4..6
   // starts the phase then), Fl[11] = phases the recurrence wave's own matrix work has finished (init mode: the helper may
-  // then reuse a beta buffer).  Each wave waits only for what it really reads, so the matrix waves -- the critical path --
+  // then reuse a beta buffer), Fl[13] = (MASK) chains that have read their cross blocks.  Each wave waits only for what it really reads, so the matrix waves -- the critical path --
   // never stop at a barrier.  LDS operations of a wave execute in order and the LDS is one pipeline per CU, so
   // "data stores; s_waitcnt lgkmcnt(0); counter store" on one side and "counter load ... ; data loads" on the other are
   // ordered; the asm memory clobbers keep the compiler from moving accesses across them.
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           for (int r = 0; r < RPG; r++) {
             double cx = 0.0;
             if constexpr (MASK) {
-              const double *gx = &LGxk[par][((hg + NG * r) * 16) * 16 + ht];
+              const double *gx = &LGxk[((hg + NG * r) * 16) * 16 + ht];
 #pragma unroll
               for (int i = 0; i < 16; i++) cx += gx[i * 16] * dlp[i];
             } else {
@@ -520,9 +521,10 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         }
         double sb = __shfl(Sown[0], ht, 64);     // S of SNP 0 (group 0) to every group
         if constexpr (MASK) {
+          signal(13, b - seg_b0 + 1);              // the single cross-block buffer is free for block b+1
           // ---- the same chain with the trait's own diagonal block (lower triangle in LGk) and per-entry sig2_beta_vb
           // (src/coreLoop.cpp:115-133): coef, K and cA come per entry from the helper
-          wait_ge(12, b - seg_b0 + 1);             // the helper has put block b's diagonal blocks into the single LGk buffer
+          const double *LGk = &LGk2[par][0];
           int rtri[RPG], rrow[RPG];
 #pragma unroll
           for (int r = 0; r < RPG; r++) { rrow[r] = hg + NG * r; rtri[r] = rrow[r] * (rrow[r] + 1) / 2; }
@@ -613,19 +615,21 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     // registers one wave cannot keep enough loads outstanding: the staging alone took 4x the phase).  hipcc drains vmcnt(0) at
     // the first use of an ordinary load's result while a DMA is pending, so every ordinary load of an iteration is consumed
     // before the DMAs are issued (the helper's own loads run one block ahead, see `pre_load`).
-    auto cross_dma = [&](int b, int par) __attribute__((always_inline)) {   // 16 cross blocks, 32 KB -> LGxk[par]
-      const char *src = (const char *)(gk_block(b) + AQ_GK_DIAG) + lane * 16;
-#pragma unroll
-      for (int i = 0; i < 32; i++) aq_glds16(src + 1024 * i, &LGxk[par][128 * i]);
-    };
-    auto diag_dma = [&](int b) __attribute__((always_inline)) {             // 16 diagonal blocks (lower triangles), 17 KB -> LGk
+    // Buffers: the diagonal blocks by block parity (read throughout the chain), the cross blocks in a single buffer that the
+    // recurrence wave releases (counter Fl[13]) right after the correction at the start of its chain -- the DMA of block b+1 has
+    // the whole chain of block b to land.
+    auto gk_dma = [&](int b, int par) __attribute__((always_inline)) {
       const char *src = (const char *)gk_block(b) + lane * 16;
 #pragma unroll
-      for (int i = 0; i < AQ_GK_DIAG / 128; i++) aq_glds16(src + 1024 * i, &LGk[128 * i]);
+      for (int i = 0; i < AQ_GK_DIAG / 128; i++) aq_glds16(src + 1024 * i, &LGk2[par][128 * i]);   // 16 lower triangles, 17 KB
+      src += AQ_GK_DIAG * 8;
+#pragma unroll
+      for (int i = 0; i < 32; i++) aq_glds16(src + 1024 * i, &LGxk[128 * i]);                      // 16 cross blocks, 32 KB
     };
     // block b -> LDS parity par.  Complete Y: loads first, the probit arithmetic covers their latency.  MASK: gam, mu and the
     // diagonal X_norm_sq(j,k) of block b were requested by pre_load(b) an iteration earlier.
     double pl_g[MASK ? RPG : 1], pl_m[MASK ? RPG : 1], pl_xn[MASK ? RPG : 1];
+    double sv_g[MASK ? RPG : 1], sv_m[MASK ? RPG : 1], sv_xn[MASK ? RPG : 1], sv_th[MASK ? RPG : 1];   // the block being staged
     auto pre_load = [&](int b) __attribute__((always_inline)) {
       const double *gk = gk_block(b);
 #pragma unroll
@@ -637,13 +641,23 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         pl_xn[r] = gk[(jj * (jj + 1) / 2 + jj) * 16 + ht];     // X_norm_sq(j,k) = the diagonal of the trait's own block
       }
     };
+    // MASK: first half of `stage` -- takes over the pre-loaded values (pinned in registers: nothing of them is waited for
+    // once the DMA is pending), starts the DMA of block b's Gram blocks and then requests the values of block b_next, which
+    // arrive behind the DMA while block b is computed
+    auto stage_dma = [&](int b, int par, int b_next) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < RPG; r++) {
+        asm volatile("" : "+v"(pl_g[r]), "+v"(pl_m[r]), "+v"(pl_xn[r]), "+v"(th[r]) : : "memory");
+        sv_g[r] = pl_g[r]; sv_m[r] = pl_m[r]; sv_xn[r] = pl_xn[r]; sv_th[r] = th[r];
+      }
+      gk_dma(b, par);
+      if (b_next < seg_b1) { pre_load(b_next); theta_load(b_next); }
+    };
     auto stage = [&](int b, int par) __attribute__((always_inline)) {
       double st_g[RPG], st_m[RPG], st_G[4], st_Gx[4], st_xn[RPG];
       if constexpr (MASK) {
 #pragma unroll
-        for (int r = 0; r < RPG; r++) { st_g[r] = pl_g[r]; st_m[r] = pl_m[r]; st_xn[r] = pl_xn[r]; }
-        asm volatile("" : "+v"(st_xn[0]) : : "memory");   // (the values are in registers by now: nothing of them is waited for below)
-        cross_dma(b, par);
+        for (int r = 0; r < RPG; r++) { st_g[r] = sv_g[r]; st_m[r] = sv_m[r]; st_xn[r] = sv_xn[r]; }
       } else {
 #pragma unroll
         for (int r = 0; r < RPG; r++) {
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #pragma unroll
       for (int r = 0; r < RPG; r++) {
         const int j = 16 * b + hg + NG * r, e = lane + 64 * r;
-        const double u = th[r] + zk;
+        const double u = (MASK ? sv_th[r] : th[r]) + zk;
         double A, imr1, imr0, ee;
         aq_probit_A_imr(u, &A, &imr1, &imr0, &ee);
         if (!a.c_is_one) {
@@ -673,14 +687,16 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         LB[par][e] = valid ? imr1 - imr0 : 0.0;
         Laa[par][e] = valid ? u + imr0 : 0.0;
         if constexpr (MASK) {
-          const double s2 = 1.0 / (a.c * (st_xn[r] + sig2_inv_h) * tau_k);     // update_sig2_beta_vb_ with X_norm_sq, R/update_vb.R:45
-          const double ls2 = log(s2);
+          const double is2 = a.c * (st_xn[r] + sig2_inv_h) * tau_k;            // update_sig2_beta_vb_ with X_norm_sq, R/update_vb.R:45
+          const double s2 = aq_recip_pos(is2);
+          const double ls2 = -aq_log_pos(is2);
           const double cf = a.c * s2 * tau_k;                                  // src/coreLoop.cpp:125
           LA[par][e] = a.c * ((valid ? A : 0.0) - 0.5 * ls2 + cstna_k);        // :127-129
           Lcoef[par][e] = cf;
           LK[par][e] = cf * cf * (a.c * 0.5 / s2);                             // coef^2 c / (2 sig2_beta): x = cA - s^2 K
           Ls2[par][e] = s2;
           Lls2[par][e] = ls2;
+          Lxn[par][e] = st_xn[r];
         } else {
           LA[par][e] = valid ? A : 0.0;
         }
@@ -688,7 +704,13 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #pragma unroll
       for (int r = 0; r < RPG; r++) Lm1[par][lane + 64 * r] = st_g[r] * st_m[r];
       if constexpr (MASK) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the cross blocks have landed in LGxk[par]
+#ifdef AQ_DIAG_TIME
+        const long long t_dma = __builtin_readcyclecounter();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Gram blocks have landed
+#ifdef AQ_DIAG_TIME
+        dg_wait += __builtin_readcyclecounter() - t_dma;   // (shows up as the helper's "waiting on matrix/recurrence")
+#endif
       } else {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -721,7 +743,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           if constexpr (MASK) {
             const double s2 = Ls2[par][e];
             const double m2 = (mu * mu + s2) * gm;                           // update_m2_beta_, R/update_vb.R:19-31
-            const double xn = 1.0 / (a.c * s2 * tau_k) - sig2_inv_h;         // X_norm_sq(j,k) back from sig2_beta_vb(j,k)
+            const double xn = Lxn[par][e];
             cs1 += m2;
             cs2 += xn * (m2 - be * be);
             cs5 += gm * Lls2[par][e];
@@ -764,32 +786,24 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       }
     } else {
       theta_load(seg_b0);
-      if constexpr (MASK) pre_load(seg_b0);
+      if constexpr (MASK) { pre_load(seg_b0); stage_dma(seg_b0, seg_b0 & 1, seg_b0 + 1); }
       stage(seg_b0, seg_b0 & 1);
-      if constexpr (MASK) {
-        diag_dma(seg_b0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        signal(12, 1);
-        if (seg_b0 + 1 < seg_b1) pre_load(seg_b0 + 1);
-      }
-      if (seg_b0 + 1 < seg_b1) theta_load(seg_b0 + 1);
       signal(7, 1);
+      if constexpr (!MASK) { if (seg_b0 + 1 < seg_b1) theta_load(seg_b0 + 1); }
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
+        if constexpr (MASK) {
+          // the Gram blocks of block b+1 go on their way as soon as the chain of block b has applied the cross blocks (which
+          // also means that block b-1, the last reader of the other diagonal buffer, is through)
+          if (b + 1 < seg_b1) { wait_ge(13, b - seg_b0 + 1); stage_dma(b + 1, par ^ 1, b + 2); }
+        }
         // block b-1 must be through the recurrence: its gam / mu are read here, and the parity buffers about to be
         // overwritten with block b+1 are the ones it read
         if (b > seg_b0) { wait_ge(6, b - seg_b0); finalize(b - 1, par ^ 1); }
         if (b + 1 < seg_b1) {
           stage(b + 1, par ^ 1);
           signal(7, b - seg_b0 + 2);
-          if constexpr (MASK) {   // the single LGk buffer is free once the chain of block b is through
-            wait_ge(6, b - seg_b0 + 1);
-            diag_dma(b + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            signal(12, b - seg_b0 + 2);
-            if (b + 2 < seg_b1) pre_load(b + 2);     // ordinary loads last: consumed an iteration later
-          }
-          if (b + 2 < seg_b1) theta_load(b + 2);
+          if constexpr (!MASK) { if (b + 2 < seg_b1) theta_load(b + 2); }
         }
       }
       wait_ge(6, nblk);
