@@ -37,9 +37,12 @@ PEAK_FP64_MFMA_MEASURED_TFLOPS = 77.8
 # HBM-side bytes of ONE core-sweep launch at the default workload on one GPU, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command with the gfx950
 # correction (FETCH_SIZE x 2 for coalesced streaming reads, calibrated on aq_k_prepass's gam read):
-# profiles/r02_pmc_hbm_traffic_v1.txt (reads 2 x 11,625,797 KB + writes 8,428,673 KB).  PMC counters cannot be read from inside
+# profiles/r02_pmc_hbm_traffic_v2.txt (reads 2 x 11,505,136 KiB + writes 8,411,633 KiB).  PMC counters cannot be read from inside
 # the timed run, so this is the profile's number for the same kernel and workload, not a value measured in this run.
-PMC_TRAFFIC_C3_BYTES = 3.24e10
+PMC_TRAFFIC_C3_BYTES = 3.22e10
+# the same workload with 5 % of Y missing (AQ_BENCH_NA=0.05: the MASK instance of the look-ahead kernel, which streams the
+# traits' own Gram blocks, 98 GB per sweep): profiles/r02_pmc_hbm_traffic_c3_na5_v1.txt (2 x 65,440,573 KiB + 8,769,789 KiB)
+PMC_TRAFFIC_C3_NA5_BYTES = 1.43e11
 
 
 def build_problem(n, p, q_total, k0, k1, device, seed=123):
@@ -272,6 +275,15 @@ def main():
         q_loc = k1 - k0
         flop_per_launch = 4.0 * n * p * q_loc                  # W_f = 4 n p q (this rank's traits)
         achieved = flop_per_launch / (core_ms * 1e-3) / 1e12
+        # gam, mu read and written once, X once, the residual once; with missing values also the traits' own diagonal
+        # and cross Gram blocks (AQ_GK_STRIDE = 6272 doubles per trait tile and SNP block) and the mask
+        algo_bytes = 32.0 * p * q_loc + 8.0 * n * p + 16.0 * n * q_loc
+        na = float(os.environ.get("AQ_BENCH_NA", "0") or 0)
+        if na > 0 and st1["core_kernel"] == 0:
+            algo_bytes += 8.0 * 6272 * ((q_loc + 15) // 16) * ((p + 15) // 16) + 1.0 * n * q_loc
+        pmc_traffic = None
+        if (n, p, q, world) == (1000, 50000, 10000, 1) and st1["core_kernel"] == 0:
+            pmc_traffic = PMC_TRAFFIC_C3_BYTES if na == 0 else (PMC_TRAFFIC_C3_NA5_BYTES if na == 0.05 else None)
         out = {
             "metric": "VB sweeps/sec", "value": args.steps / dt, "unit": "sweeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
@@ -287,9 +299,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": {0: "aq_core_sweep_la_kernel", 2: "aq_trait_wave_kernel",
                                                      3: "aq_core_sweep_mis_kernel"}[st1["core_kernel"]], "achieved": achieved,
                          "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,
-                         "traffic": PMC_TRAFFIC_C3_BYTES if (n, p, q, world) == (1000, 50000, 10000, 1) else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC passes of the same command, profiles/r02_pmc_hbm_traffic_v1.txt: a profile constant, not measured in this run)",
-                         "algorithmic_bytes": 32.0 * p * q_loc + 8.0 * n * p + 16.0 * n * q_loc,
+                         "traffic": pmc_traffic,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC passes of the same command, profiles/r02_pmc_hbm_traffic_*.txt: a profile constant, not measured in this run)",
+                         "algorithmic_bytes": algo_bytes,
                          "peak_measured_mfma_f64": PEAK_FP64_MFMA_MEASURED_TFLOPS,
                          "frac_of_measured_mfma_peak": achieved / PEAK_FP64_MFMA_MEASURED_TFLOPS,
                          "kernel_ms_avg": core_ms, "flop_per_launch": flop_per_launch},
