@@ -1161,7 +1161,7 @@ struct AqStateHeader {
   uint64_t magic;        // "AQVBST02"
   int32_t n, p, q, q_total, p_pad, q_pad, n_pad, core_kernel;
   int32_t it, converged, annealing, ind_batch_conv, batch_conv, failed, n_trace, has_missing;
-  int32_t trait_offset, reserved;   // which trait shard of a q-sharded run the state belongs to
+  int32_t trait_offset, scheme_df;  // which trait shard of a q-sharded run the state belongs to; scheme + 16 df
   double c, c_s, sig2_zeta, lb_new, lb_old;
 };
 static const uint64_t AQ_STATE_MAGIC = 0x32305453425651ull | ((uint64_t)'A' << 56);
@@ -1197,7 +1197,7 @@ extern "C" int aq_vb_get_state(aq_vb_handle s, void *buf, int64_t cap) {
   std::memset(&h, 0, sizeof(h));
   h.magic = AQ_STATE_MAGIC;
   h.n = s->n; h.p = s->p; h.q = s->q; h.q_total = s->q_total; h.p_pad = s->p_pad; h.q_pad = s->q_pad; h.n_pad = s->n_pad;
-  h.core_kernel = aq_core_kernel_id(s); h.trait_offset = s->trait_offset;
+  h.core_kernel = aq_core_kernel_id(s); h.trait_offset = s->trait_offset; h.scheme_df = s->scheme + 16 * s->df;
   h.it = s->it; h.converged = s->converged; h.annealing = s->annealing; h.ind_batch_conv = s->ind_batch_conv;
   h.batch_conv = s->batch_conv; h.failed = s->failed; h.n_trace = (int32_t)s->trace_it.size(); h.has_missing = s->has_missing;
   h.c = s->c; h.c_s = s->c_s; h.sig2_zeta = s->sig2_zeta; h.lb_new = s->lb_new; h.lb_old = s->lb_old;
@@ -1224,6 +1224,8 @@ extern "C" int aq_vb_set_state(aq_vb_handle s, const void *buf, int64_t len) {
     return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state was saved for a different problem shape or kernel geometry");
   if (h.trait_offset != s->trait_offset)
     return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state belongs to another trait shard (trait_offset differs)");
+  if (h.scheme_df != s->scheme + 16 * s->df)
+    return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state was saved under another scheme (global-local / global-only) or df");
   size_t need = sizeof(h) + (size_t)h.n_trace * (sizeof(int32_t) + sizeof(double));
   for (auto &g : aq_state_segments(s)) need += g.bytes;
   if (h.n_trace < 0 || (int64_t)need != len) return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: state size mismatch");

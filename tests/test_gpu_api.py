@@ -138,6 +138,21 @@ def test_state_of_another_problem_is_refused():
     with pytest.raises(AqError, match="not an atlasqtl-hip state blob"):
         b.set_state(np.zeros(4096, dtype=np.uint8))
     b.close()
+    # same shape, but another trait shard of a sharded run / another scheme: refused as well (header v02)
+    prob = make_problem(200, 130, 49, p_act=10)
+    c = _vbrun(prob, q_total=98, trait_offset=49)
+    with pytest.raises(AqError, match="different problem shape"):       # q_total differs
+        c.set_state(blob)
+    blob_c = c.get_state()
+    c.close()
+    d = _vbrun(prob, q_total=98, trait_offset=0)
+    with pytest.raises(AqError, match="another trait shard"):
+        d.set_state(blob_c)
+    d.close()
+    e = _vbrun(prob, scheme="global")
+    with pytest.raises(AqError, match="another scheme"):
+        e.set_state(blob)
+    e.close()
 
 
 def test_checkpoint_path_and_resume(tmp_path):

@@ -138,10 +138,11 @@ def test_vb_padding_edges():
 @pytest.mark.parametrize("chain", [0, 5])
 @pytest.mark.parametrize("shape", [(1000, 208, 40), (1008, 130, 17)])
 def test_bench_kernel_instance_matches_oracle(shape, chain, tt, stagger, monkeypatch):
-    """The instances bench.py measures -- aq_core_sweep_la_kernel<11,10,*,TT> (n = 1000 -> 63 residual tiles, NT = 11 on
-    waves 0-2, 10 on waves 4-6), with one and with two trait tiles per workgroup (C3 runs TT = 2: q = 40 pads to 4 tiles, the
-    last one all padding; q = 17 to 2 tiles, the second one partly), SIMD partners in step and staggered, plain launch and 5
-    chained SNP segments -- against the oracle over a whole annealed run."""
+    """The instances bench.py measures (n = 1000 -> 63 residual tiles): aq_core_sweep_la_kernel<10,9,*,2> -- two trait tiles
+    per workgroup, 10 tiles on waves 0-2, 9 on waves 4-6 and 6 on the recurrence wave; C3 runs this one (q = 40 pads to 4
+    tiles, the last one all padding; q = 17 to 2 tiles, the second one partly) -- and <11,10,*,1> (one tile per workgroup: the
+    trait shards of a multi-GPU run), SIMD partners in step and staggered, plain launch and 5 chained SNP segments, against
+    the oracle over a whole annealed run."""
     monkeypatch.setenv("AQ_CHAIN", str(chain))
     monkeypatch.setenv("AQ_TT", str(tt))
     monkeypatch.setenv("AQ_STAGGER", str(stagger))
@@ -158,9 +159,9 @@ def test_bench_kernel_instance_matches_oracle(shape, chain, tt, stagger, monkeyp
 @pytest.mark.parametrize("tt", [1, 2])
 @pytest.mark.parametrize("n", [20, 100, 200, 330, 512, 600, 768, 860, 1024, 1040])
 def test_look_ahead_kernel_every_tile_count_matches_oracle(n, tt, monkeypatch):
-    """Residual-tile geometries NT/NT2 = 1/1 ... 11/11 of the look-ahead kernel (n = 1040 is the largest n it takes:
-    66 tiles; beyond 1056 the masked kernel runs), one and two trait tiles per workgroup, 12 sweeps each incl. the ladder and
-    two ELBO evaluations."""
+    """Residual-tile geometries NT/NT2 = 1/1 ... 11/11 of the look-ahead kernel (n = 1040: 65 of the 66 tiles one workgroup
+    holds; beyond n = 1056 the sample axis is split over several workgroups, tests/test_gpu_sharded.py), one and two trait
+    tiles per workgroup, 12 sweeps each incl. the ladder and two ELBO evaluations."""
     monkeypatch.setenv("AQ_TT", str(tt))
     prob = make_problem(n, 100, 24, p_act=6, prob_assoc=0.5)
     ref, got, tr = _run_both(prob, (1, 2, 10), 12, thinned=False)
