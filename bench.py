@@ -238,7 +238,7 @@ def main():
     X, Y, lh, li = build_problem(n, p, q, k0, k1, local_rank)
     anneal = (1, 2, 10)
     run = VbRun(Y, X, lh, li, anneal, tol=1e-12, maxit=args.warmup + args.steps + 5, thinned_elbo_eval=True,
-                debug=False, device=local_rank, q_total=q, process_group=pg)
+                debug=False, device=local_rank, q_total=q, process_group=pg, trait_offset=k0)
     del li
     torch.cuda.empty_cache()
     t_setup = time.time() - t_setup
