@@ -174,13 +174,15 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   __shared__ double LGxk[MASK ? 4096 : 1];
   __shared__ double Lcoef[2][MASK ? ENT : 1], LK[2][MASK ? ENT : 1], Ls2[2][MASK ? ENT : 1], Lls2[2][MASK ? ENT : 1], Lxn[2][MASK ? ENT : 1];
   __shared__ double Lgam[2][ENT], Lmu[2][ENT], Ldel[2][ENT];
+  __shared__ double Stot[(SEG || TT == 2) ? 1 : 2][(SEG || TT == 2) ? 1 : ENT];   // sample split: S' of a block summed over all parts (from the helper wave)
   __shared__ double Lred[6][64];       // the helper lanes' column sums [row group][trait], added up per trait at the end
   __shared__ double Lrn[NPS * 4][NTR];
   // Point-to-point progress counters instead of a workgroup barrier per phase: Fl[0..5] = number of SNP blocks whose
   // partial S' matrix wave m has written, Fl[6] = blocks the recurrence wave has finished, Fl[7] = blocks the helper
   // wave has staged, Fl[8..10] = phases that matrix wave 0..2 has carried past its stagger tile (its SIMD partner 4..6
   // starts the phase then), Fl[11] = phases the recurrence wave's own matrix work has finished (init mode: the helper may
-  // then reuse a beta buffer), Fl[13] = (MASK) chains that have read their cross blocks.  Each wave waits only for what it really reads, so the matrix waves -- the critical path --
+  // then reuse a beta buffer), Fl[13] = (MASK) chains that have read their cross blocks, Fl[14] = (sample split) blocks whose
+  // S' the helper wave has exchanged with the other parts.  Each wave waits only for what it really reads, so the matrix waves -- the critical path --
   // never stop at a barrier.  LDS operations of a wave execute in order and the LDS is one pipeline per CU, so
   // "data stores; s_waitcnt lgkmcnt(0); counter store" on one side and "counter load ... ; data loads" on the other are
   // ordered; the asm memory clobbers keep the compiler from moving accesses across them.
@@ -432,6 +434,47 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   };
   const auto no_hook = [](int) {};
 
+  // ---- sample split (C > 1): publish this part's partial S' of block b (lane = (row group, trait), own[r] = row hg + NG r),
+  // collect the others', add in fixed order; on return own[] holds the sum over all parts, the same bits in every part.
+  // Run by the recurrence wave at the start of its chain, or -- a.xhelper, chosen by the host when the matrix waves' phase is
+  // longer than chain + exchange -- by the helper wave a block ahead.  All exchanged words are agent-scope atomics (sc1: written
+  // through to, and read from, the level the XCDs share), ordered by program order + s_waitcnt.  No release / acquire fence:
+  // at agent scope it would write back and invalidate this XCD's whole L2, where the X operand panels live.  Slots alternate
+  // by block parity: a part overwrites the slot of block b with block b+2 only after its own exchange of block b+1, i.e. after
+  // every other part has published b+1 -- which each does after having read block b.
+  bool split_dead = false;   // a bounded wait on a partner expired (reported through errflag)
+  auto split_exchange = [&](int b, double (&own)[RPG]) __attribute__((always_inline)) {
+    const int par = b & 1, kdone = b - seg_b0 + 1;
+    double *slot = a.Pbuf + ((size_t)(wg * 2 + par) * C) * ENT + lane;
+#pragma unroll
+    for (int r = 0; r < RPG; r++)
+      __hip_atomic_store(&slot[(size_t)part * ENT + 64 * r], own[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial is performed before the flag goes up
+    if (lane == 0) __hip_atomic_store(&a.pflag[wg * C + part], kdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (!split_dead) {   // lane c polls part c's flag
+      int f = kdone;
+      if (lane < C && lane != part) f = __hip_atomic_load(&a.pflag[wg * C + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(f >= kdone)) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) { *a.errflag = 1; split_dead = true; }   // give up for good: results are invalid
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // flags observed before the partials are requested
+    double tot[RPG];
+#pragma unroll
+    for (int r = 0; r < RPG; r++) tot[r] = 0.0;
+    for (int c2 = 0; c2 < C; c2++) {
+      double pv[RPG];
+#pragma unroll
+      for (int r = 0; r < RPG; r++)
+        pv[r] = __hip_atomic_load(&slot[(size_t)c2 * ENT + 64 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int r = 0; r < RPG; r++) tot[r] += (c2 == part) ? own[r] : pv[r];
+    }
+#pragma unroll
+    for (int r = 0; r < RPG; r++) own[r] = tot[r];
+  };
+
   __syncthreads();   // counters and the helper's LDS initialisation are visible to every role
   if (is_rec) {
     // =========================== recurrence wave ===========================================
@@ -440,63 +483,36 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const double rc_cinv2s = MASK ? 0.0 : a.c * a.inv2s[ktrait];
       const double rc_cst = MASK ? 0.0 : a.cst[ktrait];
       const double rc_K = rc_coef * rc_coef * rc_cinv2s;   // keeps mu off the dependency chain of the recursion
-      bool split_dead = false;   // a bounded wait on a partner expired (reported through errflag)
       auto chain_block = [&](int b) __attribute__((always_inline)) {
         const int par = b & 1;
-        {   // block b needs its six partial S' and its staged scalars
-          const int need = b - seg_b0 + 1;
-#pragma unroll
-          for (int m = 0; m < NWM; m++) wait_ge(m, need);
-          wait_ge(7, need);
-        }
         // ---- SNP block b.  lane = (hg, ht): ht = trait, hg one of NG row groups -------------------------------------
         // This wave and the helper wave share one SIMD and both are bound by its fp64 VALU issue rate (a dependent
         // v_fma_f64 has a latency of only 6 cycles, tools/microbench/f64_valu.hip), so everything that does not belong
         // to the chain itself is spread over the row groups instead of being repeated in each of them:
         // group hg owns the rows hg, hg + NG, ... of S.
         double Sown[RPG];
+        const int need = b - seg_b0 + 1;
+        if (C > 1 && a.xhelper) {
+          // sample split: the helper wave has added this part's partial S' to the other parts' (a block ahead, off this
+          // wave's critical path) -- every part reads the same bits and runs the same chain
+          wait_ge(14, need);
+          wait_ge(7, need);
 #pragma unroll
-        for (int r = 0; r < RPG; r++) {
-          const int j = hg + NG * r;
-          double sv = Sp[par][0][j * NTR + ht];
+          for (int r = 0; r < RPG; r++) Sown[r] = Stot[par][(hg + NG * r) * NTR + ht];
+        } else {
+          // block b needs its six partial S' and its staged scalars
 #pragma unroll
-          for (int ww = 1; ww < NPS; ww++) sv += Sp[par][ww][j * NTR + ht];
-          Sown[r] = sv;
-        }
-        if (C > 1) {
-          // ---- sample split: publish this part's partial S', collect the others', add in fixed order ----
-          // All exchanged words are agent-scope atomics (sc1: written through to, and read from, the level the XCDs share),
-          // ordered by program order + s_waitcnt.  No release / acquire fence: at agent scope it would write back and
-          // invalidate this XCD's whole L2, where the X operand panels live.
-          const int kdone = b - seg_b0 + 1;
-          double *slot = a.Pbuf + ((size_t)(wg * 2 + par) * C) * ENT + lane;
+          for (int m = 0; m < NWM; m++) wait_ge(m, need);
+          wait_ge(7, need);
 #pragma unroll
-          for (int r = 0; r < RPG; r++)
-            __hip_atomic_store(&slot[(size_t)part * ENT + 64 * r], Sown[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial is performed before the flag goes up
-          if (lane == 0) __hip_atomic_store(&a.pflag[wg * C + part], kdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          int spins = 0;
-          while (!split_dead) {   // lane c polls part c's flag
-            int f = kdone;
-            if (lane < C && lane != part) f = __hip_atomic_load(&a.pflag[wg * C + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(f >= kdone)) break;
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 22)) { *a.errflag = 1; split_dead = true; }   // give up for good: results are invalid
+          for (int r = 0; r < RPG; r++) {
+            const int j = hg + NG * r;
+            double sv = Sp[par][0][j * NTR + ht];
+#pragma unroll
+            for (int ww = 1; ww < NPS; ww++) sv += Sp[par][ww][j * NTR + ht];
+            Sown[r] = sv;
           }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // flags observed before the partials are requested
-          double tot[RPG];
-#pragma unroll
-          for (int r = 0; r < RPG; r++) tot[r] = 0.0;
-          for (int c2 = 0; c2 < C; c2++) {
-            double pv[RPG];
-#pragma unroll
-            for (int r = 0; r < RPG; r++)
-              pv[r] = __hip_atomic_load(&slot[(size_t)c2 * ENT + 64 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int r = 0; r < RPG; r++) tot[r] += (c2 == part) ? Sown[r] : pv[r];
-          }
-#pragma unroll
-          for (int r = 0; r < RPG; r++) Sown[r] = tot[r];
+          if constexpr (!SEG && TT == 1) { if (C > 1) split_exchange(b, Sown); }
         }
         if (b > seg_b0) {
           // cross-block correction X_b'X_{b-1} delta_{b-1} of this group's rows (a segment starts from a complete residual);
@@ -756,6 +772,26 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         if ((ht & 15) == 0 && lead) a.rowGB[(size_t)(tile0 + (ht >> 4)) * a.p_pad + j] = gb;
       }
     };
+    // sample split, exchange on this wave (a.xhelper): a block ahead of the chain -- S' of block b is complete a phase before the
+    // chain of block b starts -- so the round trip through the shared cache level is off the recurrence wave's path
+    auto exchange = [&](int b) __attribute__((always_inline)) {
+      const int par = b & 1, kdone = b - seg_b0 + 1;
+#pragma unroll
+      for (int m = 0; m < NWM; m++) wait_ge(m, kdone);
+      double own[RPG];
+#pragma unroll
+      for (int r = 0; r < RPG; r++) {
+        const int e = lane + 64 * r;
+        double sv = Sp[par][0][e];
+#pragma unroll
+        for (int ww = 1; ww < NPS; ww++) sv += Sp[par][ww][e];
+        own[r] = sv;
+      }
+      split_exchange(b, own);
+#pragma unroll
+      for (int r = 0; r < RPG; r++) Stot[par][lane + 64 * r] = own[r];
+      signal(14, kdone);
+    };
     if (a.mode == 1) {
       // init mode: R = Y - X beta.  This wave plays the recurrence's part: beta of block k goes where delta would (Ldel, by block
       // parity) and is announced on the recurrence counter; the matrix waves apply it in their phase k + 2, whose end they
@@ -789,6 +825,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       if constexpr (MASK) { pre_load(seg_b0); stage_dma(seg_b0, seg_b0 & 1, seg_b0 + 1); }
       stage(seg_b0, seg_b0 & 1);
       signal(7, 1);
+      if constexpr (!SEG && TT == 1) { if (C > 1 && a.xhelper) exchange(seg_b0); }
       if constexpr (!MASK) { if (seg_b0 + 1 < seg_b1) theta_load(seg_b0 + 1); }
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
@@ -803,6 +840,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         if (b + 1 < seg_b1) {
           stage(b + 1, par ^ 1);
           signal(7, b - seg_b0 + 2);
+          if constexpr (!SEG && TT == 1) { if (C > 1 && a.xhelper) exchange(b + 1); }
           if constexpr (!MASK) { if (b + 2 < seg_b1) theta_load(b + 2); }
         }
       }

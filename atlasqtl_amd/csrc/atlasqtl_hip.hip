@@ -164,6 +164,7 @@ struct aq_vb {
   int *pflag = nullptr;
   double *Xcm = nullptr, *mis = nullptr, *XN = nullptr;
   int ncu = 256;
+  int la_xhelper = 0;       // sample split of the look-ahead kernel: exchange on the helper wave (long matrix phases) or on the recurrence wave
   int chain = 0;            // > 1: chained-segment launch with that many SNP segments (aq_core_sweep_la.h, SEG)
   int *done = nullptr, *errflag = nullptr;
   bool pre_done = false;
@@ -310,7 +311,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
   } else if (s->use_la) {
     const unsigned nwg = (unsigned)(s->ntile / s->TT);
     a.done = s->done; a.errflag = s->errflag; a.stagger = s->stagger;
-    a.C = s->laC; a.Pbuf = s->Pbuf; a.pflag = s->pflag; a.rnpart = s->rnpart;
+    a.C = s->laC; a.xhelper = s->la_xhelper; a.Pbuf = s->Pbuf; a.pflag = s->pflag; a.rnpart = s->rnpart;
     a.mis = s->mis; a.GK = s->GK; a.tau = s->tau; a.log_tau = s->log_tau;
     a.sig2_inv_p = &s->sc->sig2_inv; a.log_sig2_inv_p = &s->sc->log_sig2_inv;
     if (s->laC > 1) AQ_HIP(hipMemsetAsync(s->pflag, 0, (size_t)s->ntile * s->laC * sizeof(int), 0));
@@ -556,6 +557,12 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
             if (cost < best - 1e-9) { best = cost; s->laC = C; s->NT = NT; s->NT2 = NT2; s->n_pad = 16 * tiles * C; }
           }
           if (best >= 1e300) { delete s; return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead geometry for this n"); }
+          // Who exchanges the partial S': the recurrence wave at the start of its chain (period = chain + exchange, 5.5 us), or
+          // the helper wave a block ahead (its own staging + exchange, ~6 us, but off the chain's path).  The second pays once
+          // the matrix waves' phase is the longer one -- measured: n = 1500 (16 tiles per SIMD) 70.8 vs 78.9 ms, n = 2500 (18)
+          // 136.1 vs 134.4, n = 5000 (21) 236.1 vs 225.2.  (AQ_LA_XHELPER=0/1 pins it: test hook.)
+          s->la_xhelper = (s->NT + s->NT2 >= 18) ? 1 : 0;
+          if (const char *e = getenv("AQ_LA_XHELPER")) s->la_xhelper = atoi(e) != 0;
         }
         if (s->TT == 2) s->stagger = (s->NT + 2) / 3;
       }

@@ -287,7 +287,7 @@ def test_sharded_core_function_with_device_init_reproduces_single_gpu(tmp_path):
 
 
 @pytest.mark.parametrize("env", [{"AQ_MIS_C": "3", "AQ_KERNEL": "3"}, {"AQ_CHAIN": "4"}, {"AQ_LA_C": "2"},
-                                 {"AQ_LA_C": "2", "NA": "1"}])
+                                 {"AQ_LA_C": "2", "NA": "1"}, {"AQ_LA_C": "2", "AQ_LA_XHELPER": "1"}])
 def test_expired_in_kernel_wait_is_reported_everywhere(env, monkeypatch):
     """A bounded wait that expires inside a sweep kernel (sample split: a partner's partial S; chained segments: the
     previous segment's residual) raises a device flag: results are invalid.  The flag is forced through the test hook;

@@ -153,13 +153,16 @@ def test_large_n_matches_oracle(shape, na, force_old, monkeypatch):
     _check_against_oracle(make_problem(n, p, q, p_act=6, prob_assoc=0.5, na_frac=na), q, kernel=3 if force_old else 0)
 
 
+@pytest.mark.parametrize("xhelper", [0, 1])
 @pytest.mark.parametrize("C", [2, 3, 5, 8])
 @pytest.mark.parametrize("shape", [(300, 130, 49), (200, 90, 33), (1000, 64, 17)])
-def test_look_ahead_kernel_sample_split_matches_oracle(shape, C, monkeypatch):
+def test_look_ahead_kernel_sample_split_matches_oracle(shape, C, xhelper, monkeypatch):
     """The cross-workgroup exchange of the look-ahead kernel's partial S' (agent-scope stores + flags, the same chain run
-    redundantly in every part) forced at small n with AQ_LA_C."""
+    redundantly in every part) forced at small n with AQ_LA_C; the exchange run by the recurrence wave at the start of its
+    chain and by the helper wave a block ahead (the host's choice for long matrix phases)."""
     from tests.util import make_problem
     monkeypatch.setenv("AQ_LA_C", str(C))
+    monkeypatch.setenv("AQ_LA_XHELPER", str(xhelper))
     n, p, q = shape
     _check_against_oracle(make_problem(n, p, q, p_act=8, prob_assoc=0.3), q, kernel=0)
 
@@ -199,7 +202,7 @@ def test_masked_mfma_kernel_matches_oracle(shape, na, monkeypatch):
     _check_against_oracle(make_problem(n, p, q, p_act=min(6, p // 3), prob_assoc=1.0 if q <= 20 else 0.3, na_frac=na), q, kernel=3)
 
 
-@pytest.mark.parametrize("env", [{}, {"AQ_CHAIN": "3"}, {"AQ_LA_C": "2"}, {"AQ_LA_C": "5"}])
+@pytest.mark.parametrize("env", [{}, {"AQ_CHAIN": "3"}, {"AQ_LA_C": "2"}, {"AQ_LA_C": "5"}, {"AQ_LA_C": "3", "AQ_LA_XHELPER": "1"}])
 @pytest.mark.parametrize("shape,na", [((70, 17, 1), 0.1), ((128, 40, 16), 0.3), ((200, 90, 33), 0.08), ((300, 130, 49), 0.02),
                                       ((600, 50, 20), 0.05), ((1000, 64, 18), 0.05)])
 def test_look_ahead_mask_kernel_matches_oracle(shape, na, env, monkeypatch):
