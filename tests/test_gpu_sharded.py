@@ -37,8 +37,15 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_single_process(tmp_path):
+@pytest.mark.parametrize("env", [{}, {"AQ_CHAIN": "3"}, {"AQ_LA_C": "2"}, {"AQ_LA_C": "3", "AQ_LA_XHELPER": "1"}])
+def test_two_ranks_one_gpu_match_single_process(env, tmp_path, monkeypatch):
+    """Two processes share the GPU (their kernels compete for CUs), plain and with the launches whose workgroups wait for one
+    another -- chained SNP segments, sample split with either exchange wave: the hand-offs assume that a workgroup's
+    predecessor / partners are resident or dispatched next; a violation would surface as
+    AQ_ERR_DEVICE from the bounded waits, never as a hang."""
     import torch.multiprocessing as mp
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     import atlasqtl_amd as A
     from tests.util import make_problem
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
