@@ -329,8 +329,13 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     if (chained) AQ_HIP(hipMemsetAsync(s->done, 0, (size_t)s->ntile * sizeof(int), 0));
     // chained-segment launch: chain * nwg workgroups, workgroup s*nwg + k = SNP segment s of trait-tile group k
     const unsigned grid = chained ? (unsigned)((long long)s->chain * nwg) : nwg * (unsigned)s->laC;
+    // Annealed sweeps (c != 1): the helper wave evaluates the probit terms twice and SIMD 3 becomes the bound (42 ms against 35
+    // at C3), so the recurrence wave gives three of its six residual tiles back to the matrix waves: geometry (NT, NT, 3)
+    // instead of (NT, NT - 1, 6) -- the same 6 NT + 3 tiles, hence the same n_pad and residual layout in HBM (38.5 ms).
+    int NT2l = s->NT2;
+    if (s->TT == 2 && !a.c_is_one && mode == 0 && s->NT2 == s->NT - 1 && aq_la_nt3(s->NT, s->NT2, 2) == 6 && !getenv("AQ_NT3")) NT2l = s->NT;
     int lrc = s->la_mask ? aq_la_launch_mask(s->NT, s->NT2, chained, grid, 0, a)
-              : s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
+              : s->TT == 2 ? aq_la_launch_tt2(s->NT, NT2l, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
     if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
     if (chained) {
       if (s->la_mask) hipLaunchKernelGGL(aq_k_combine_segment_sums6, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
@@ -539,7 +544,9 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         };
         if (pr->n <= 1056 && !getenv("AQ_LA_C")) {
           s->laC = 1;
-          s->n_pad = 16 * fit(ntiles, 11, &s->NT, &s->NT2);      // n <= 1056 always fits (11, 11)
+          const int tiles = fit(ntiles, 11, &s->NT, &s->NT2);    // n <= 1056 always fits (11, 11) ...
+          if (tiles >= (1 << 30)) { delete s; return aq_fail(AQ_ERR_ARG, "AQ_NT3 excludes every look-ahead geometry for this n"); }   // ... unless the test hook forbids it
+          s->n_pad = 16 * tiles;
         } else {
           // n beyond one workgroup's registers: C workgroups share a trait group (sample split, one tile per workgroup).  Cost of
           // a sweep ~ rounds of workgroups x time per SNP block: the MFMA stream of one SIMD (0.213 us per residual tile) or the
