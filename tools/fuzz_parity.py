@@ -1,5 +1,6 @@
 """Randomised parity sweep: random small shapes (ragged n, p, q; with and without missing values; with and without
-annealing) through the HIP path against the oracle.  usage: python tools/fuzz_parity.py [ncases] [seed]"""
+annealing) through the HIP path against the oracle.  usage: python tools/fuzz_parity.py [ncases] [seed]
+(AQ_FUZZ_NMAX / AQ_FUZZ_PMAX / AQ_FUZZ_QMAX widen the shape ranges, e.g. AQ_FUZZ_NMAX=1300 crosses the sample-split boundary)"""
 import os
 import sys
 import time
@@ -18,9 +19,9 @@ def run(ncases=30, seed=2024):
     worst = dict(elbo=0.0, mu=0.0, gam=0.0)
     t0 = time.time()
     for c in range(ncases):
-        n = int(rng.integers(20, 400))
-        p = int(rng.integers(12, 160))
-        q = int(rng.integers(1, 70))
+        n = int(rng.integers(20, int(os.environ.get("AQ_FUZZ_NMAX", 400))))
+        p = int(rng.integers(12, int(os.environ.get("AQ_FUZZ_PMAX", 160))))
+        q = int(rng.integers(1, int(os.environ.get("AQ_FUZZ_QMAX", 70))))
         na = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
         anneal = [None, (1, 2, 10), (2, 3, 5), (3, 2, 4)][int(rng.integers(0, 4))]
         prob = make_problem(n, p, q, p_act=max(1, min(8, p // 3)), prob_assoc=0.4, na_frac=na, seed=int(rng.integers(1, 10**6)),
