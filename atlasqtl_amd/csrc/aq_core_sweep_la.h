@@ -778,6 +778,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const int par = b & 1, kdone = b - seg_b0 + 1;
 #pragma unroll
       for (int m = 0; m < NWM; m++) wait_ge(m, kdone);
+      if constexpr (NT3 > 0) wait_ge(11, kdone);   // the recurrence wave's own tiles
       double own[RPG];
 #pragma unroll
       for (int r = 0; r < RPG; r++) {
