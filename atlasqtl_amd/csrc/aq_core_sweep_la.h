@@ -437,39 +437,63 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   // ---- sample split (C > 1): publish this part's partial S' of block b (lane = (row group, trait), own[r] = row hg + NG r),
   // collect the others', add in fixed order; on return own[] holds the sum over all parts, the same bits in every part.
   // Run by the recurrence wave at the start of its chain, or -- a.xhelper, chosen by the host when the matrix waves' phase is
-  // longer than chain + exchange -- by the helper wave a block ahead.  All exchanged words are agent-scope atomics (sc1: written
-  // through to, and read from, the level the XCDs share), ordered by program order + s_waitcnt.  No release / acquire fence:
-  // at agent scope it would write back and invalidate this XCD's whole L2, where the X operand panels live.  Slots alternate
-  // by block parity: a part overwrites the slot of block b with block b+2 only after its own exchange of block b+1, i.e. after
-  // every other part has published b+1 -- which each does after having read block b.
+  // longer than chain + exchange -- by the helper wave a block ahead.
+  // Every exchanged 64-bit word validates itself: its two lowest mantissa bits carry a tag 1..3 that changes with every use of
+  // the slot (slots alternate by block parity and start zeroed: tag 0), so there is no flag, no store acknowledgement to wait for
+  // and no ordering between words to rely on -- one trip through the level the XCDs share (sc1 atomics) instead of three.  A
+  // reader polls the words until they carry the expected tag.  The sum uses the tagged words themselves (this part's included),
+  // i.e. partial sums rounded to 2^-50 relative: identical in every part.  A part overwrites the slot of block b with block b+2
+  // only after its own exchange of block b+1, i.e. after every other part has published b+1 -- which each does after having read
+  // block b -- so a reader can only ever meet the previous or the expected tag.  No release / acquire fence: at agent scope it
+  // would write back and invalidate this XCD's whole L2, where the X operand panels live.
   bool split_dead = false;   // a bounded wait on a partner expired (reported through errflag)
-  auto split_exchange = [&](int b, double (&own)[RPG]) __attribute__((always_inline)) {
-    const int par = b & 1, kdone = b - seg_b0 + 1;
-    double *slot = a.Pbuf + ((size_t)(wg * 2 + par) * C) * ENT + lane;
+  auto split_exchange = [&](int b, double (&own)[RPG], auto meanwhile) __attribute__((always_inline)) {
+    const int par = b & 1;
+    const unsigned long long tag = 1ull + (unsigned long long)(((b - seg_b0) >> 1) % 3);
+    unsigned long long *slot = (unsigned long long *)a.Pbuf + ((size_t)(wg * 2 + par) * C) * ENT + lane;
+    unsigned long long mine[RPG];
 #pragma unroll
-    for (int r = 0; r < RPG; r++)
-      __hip_atomic_store(&slot[(size_t)part * ENT + 64 * r], own[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial is performed before the flag goes up
-    if (lane == 0) __hip_atomic_store(&a.pflag[wg * C + part], kdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (!split_dead) {   // lane c polls part c's flag
-      int f = kdone;
-      if (lane < C && lane != part) f = __hip_atomic_load(&a.pflag[wg * C + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__all(f >= kdone)) break;
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 22)) { *a.errflag = 1; split_dead = true; }   // give up for good: results are invalid
+    for (int r = 0; r < RPG; r++) {
+      mine[r] = ((unsigned long long)__double_as_longlong(own[r]) & ~3ull) | tag;
+      __hip_atomic_store(&slot[(size_t)part * ENT + 64 * r], mine[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // flags observed before the partials are requested
+    meanwhile();   // work of the caller that does not depend on the sum, while the words travel
     double tot[RPG];
 #pragma unroll
     for (int r = 0; r < RPG; r++) tot[r] = 0.0;
-    for (int c2 = 0; c2 < C; c2++) {
-      double pv[RPG];
+    // partners in ascending order (the fixed order of the sum), the next partner's words requested before the current one's
+    // are checked: with everything already published the whole collection costs one trip, not one per partner
+    unsigned long long cur[RPG], nxt[RPG];
+    auto request = [&](int c2, unsigned long long (&dst)[RPG]) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < RPG; r++)
-        pv[r] = __hip_atomic_load(&slot[(size_t)c2 * ENT + 64 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dst[r] = __hip_atomic_load(&slot[(size_t)c2 * ENT + 64 * r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    request(part == 0 ? 1 : 0, cur);
+    for (int c2 = 0; c2 < C; c2++) {
+      if (c2 == part) {
 #pragma unroll
-      for (int r = 0; r < RPG; r++) tot[r] += (c2 == part) ? own[r] : pv[r];
+        for (int r = 0; r < RPG; r++) tot[r] += __longlong_as_double((long long)mine[r]);
+        continue;
+      }
+      int cn = c2 + 1;
+      if (cn == part) cn++;
+      if (cn < C) request(cn, nxt);
+      int spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < RPG; r++) ok = ok && ((cur[r] & 3ull) == tag);
+        if (__all(ok) || split_dead) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { *a.errflag = 1; split_dead = true; }   // give up for good: results are invalid
+        request(c2, cur);
+      }
+#pragma unroll
+      for (int r = 0; r < RPG; r++) {
+        tot[r] += __longlong_as_double((long long)cur[r]);
+        cur[r] = nxt[r];
+      }
     }
 #pragma unroll
     for (int r = 0; r < RPG; r++) own[r] = tot[r];
@@ -512,29 +536,49 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
             for (int ww = 1; ww < NPS; ww++) sv += Sp[par][ww][j * NTR + ht];
             Sown[r] = sv;
           }
-          if constexpr (!SEG && TT == 1) { if (C > 1) split_exchange(b, Sown); }
         }
-        if (b > seg_b0) {
-          // cross-block correction X_b'X_{b-1} delta_{b-1} of this group's rows (a segment starts from a complete residual);
-          // MASK: with the trait's own cross block X_b' diag(mis_k) X_{b-1}
-          double dlp[16];
+        // cross-block correction X_b'X_{b-1} delta_{b-1} of this group's rows (a segment starts from a complete residual);
+        // MASK: with the trait's own cross block X_b' diag(mis_k) X_{b-1}.  It does not depend on S': with the sample split it
+        // is computed while the partial sums travel.
+        // `correction(sub)`: sub = true subtracts straight from Sown (the form the two-tile instances need: no extra registers),
+        // sub = false leaves the terms in cxs[] for later
+        double cxs[(!SEG && TT == 1) ? RPG : 1];
+        auto correction = [&](auto subc) __attribute__((always_inline)) {
+          constexpr bool sub = decltype(subc)::value;
+          if (b > seg_b0) {
+            double dlp[16];
 #pragma unroll
-          for (int i = 0; i < 16; i++) dlp[i] = Ldel[par ^ 1][i * NTR + ht];
+            for (int i = 0; i < 16; i++) dlp[i] = Ldel[par ^ 1][i * NTR + ht];
 #pragma unroll
-          for (int r = 0; r < RPG; r++) {
-            double cx = 0.0;
-            if constexpr (MASK) {
-              const double *gx = &LGxk[((hg + NG * r) * 16) * 16 + ht];
+            for (int r = 0; r < RPG; r++) {
+              double cx = 0.0;
+              if constexpr (MASK) {
+                const double *gx = &LGxk[((hg + NG * r) * 16) * 16 + ht];
 #pragma unroll
-              for (int i = 0; i < 16; i++) cx += gx[i * 16] * dlp[i];
-            } else {
-              const double *gx = &LGx[par][(hg + NG * r) * 16];
+                for (int i = 0; i < 16; i++) cx += gx[i * 16] * dlp[i];
+              } else {
+                const double *gx = &LGx[par][(hg + NG * r) * 16];
 #pragma unroll
-              for (int i = 0; i < 16; i++) cx += gx[i] * dlp[i];
+                for (int i = 0; i < 16; i++) cx += gx[i] * dlp[i];
+              }
+              if constexpr (sub) Sown[r] -= cx;
+              else cxs[r] = cx;
             }
-            Sown[r] -= cx;
+          } else if constexpr (!sub) {
+#pragma unroll
+            for (int r = 0; r < RPG; r++) cxs[r] = 0.0;
+          }
+        };
+        bool corrected = false;
+        if constexpr (!SEG && TT == 1) {
+          if (C > 1 && !a.xhelper) {
+            split_exchange(b, Sown, [&]() __attribute__((always_inline)) { correction(std::false_type{}); });
+#pragma unroll
+            for (int r = 0; r < RPG; r++) Sown[r] -= cxs[r];
+            corrected = true;
           }
         }
+        if (!corrected) correction(std::true_type{});
         double sb = __shfl(Sown[0], ht, 64);     // S of SNP 0 (group 0) to every group
         if constexpr (MASK) {
           signal(13, b - seg_b0 + 1);              // the single cross-block buffer is free for block b+1
@@ -788,7 +832,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         for (int ww = 1; ww < NPS; ww++) sv += Sp[par][ww][e];
         own[r] = sv;
       }
-      split_exchange(b, own);
+      split_exchange(b, own, [] {});
 #pragma unroll
       for (int r = 0; r < RPG; r++) Stot[par][lane + 64 * r] = own[r];
       signal(14, kdone);

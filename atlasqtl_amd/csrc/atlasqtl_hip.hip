@@ -314,7 +314,8 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     a.C = s->laC; a.xhelper = s->la_xhelper; a.Pbuf = s->Pbuf; a.pflag = s->pflag; a.rnpart = s->rnpart;
     a.mis = s->mis; a.GK = s->GK; a.tau = s->tau; a.log_tau = s->log_tau;
     a.sig2_inv_p = &s->sc->sig2_inv; a.log_sig2_inv_p = &s->sc->log_sig2_inv;
-    if (s->laC > 1) AQ_HIP(hipMemsetAsync(s->pflag, 0, (size_t)s->ntile * s->laC * sizeof(int), 0));
+    if (s->laC > 1 && mode == 0)   // the exchange slots start with tag 0 (aq_core_sweep_la.h, split_exchange)
+      AQ_HIP(hipMemsetAsync(s->Pbuf, 0, (size_t)s->ntile * 2 * s->laC * 256 * sizeof(double), 0));
     a.dbg = nullptr;
     static long long *dbg_buf = nullptr;   // AQ_DIAG_DUMP=<file> with a -DAQ_DIAG_TIME build: per-role wait / total cycles of sweep 15
     const char *dump = getenv("AQ_DIAG_DUMP");
@@ -547,10 +548,26 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
           const int tiles = fit(ntiles, 11, &s->NT, &s->NT2);    // n <= 1056 always fits (11, 11) ...
           if (tiles >= (1 << 30)) { delete s; return aq_fail(AQ_ERR_ARG, "AQ_NT3 excludes every look-ahead geometry for this n"); }   // ... unless the test hook forbids it
           s->n_pad = 16 * tiles;
+          // Few trait groups (a trait shard of a multi-GPU run, a small q): the CUs left idle share the samples.  Per SNP block an
+          // unsplit workgroup needs its MFMA stream (0.213 us per residual tile of one SIMD + 1.0 of hand-offs; n = 1000: 5.46 us
+          // measured) or, for small n, the chain (3.3 us); a part of a split group needs its shorter stream or chain + exchange
+          // (4.5 us with two parts, measured at n = 1000: 4.53; + 0.2 per further part).  All parts must run at once.
+          // (Not with missing values: there the chain is longer and the helper wave loaded -- q = 1250 with 5 % NA: 19.3 ms unsplit,
+          // 20.1 split.  AQ_LA_NOSPLIT=1 keeps one workgroup per group: experiments.)
+          if (s->TT == 1 && !s->la_mask && !getenv("AQ_LA_NOSPLIT")) {
+            double best = std::max(0.213 * (s->NT + s->NT2) + 1.0, 3.3) * 0.95;   // a split must win by 5 %
+            for (int C = 2; C <= 8 && (long long)s->ntile * C <= s->ncu; C++) {
+              int NT = 0, NT2 = 0;
+              const int tiles_c = fit((ntiles + C - 1) / C, 18, &NT, &NT2);
+              if (tiles_c >= (1 << 30)) continue;
+              const double cost = std::max(0.213 * (NT + NT2) + 1.0, 4.5 + 0.2 * (C - 2));
+              if (cost < best - 1e-9) { best = cost; s->laC = C; s->NT = NT; s->NT2 = NT2; s->n_pad = 16 * tiles_c * C; }
+            }
+          }
         } else {
           // n beyond one workgroup's registers: C workgroups share a trait group (sample split, one tile per workgroup).  Cost of
           // a sweep ~ rounds of workgroups x time per SNP block: the MFMA stream of one SIMD (0.213 us per residual tile) or the
-          // exchange + chain (~8 us), whichever is longer.  (AQ_LA_C forces the split at small n: test hook.)
+          // exchange + chain (4.5 us with two parts, + 0.2 per further part), whichever is longer.  (AQ_LA_C forces the split at small n: test hook.)
           s->TT = 1; s->q_pad = (pr->q + 15) / 16 * 16; s->ntile = s->q_pad / 16; s->stagger = 0;
           double best = 1e300;
           const char *ec = getenv("AQ_LA_C");
@@ -560,17 +577,16 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
             const int tiles = fit((ntiles + C - 1) / C, 18, &NT, &NT2);
             if (tiles >= (1 << 30)) continue;
             const double rounds = (double)(((long long)s->ntile * C + s->ncu - 1) / s->ncu);
-            const double cost = rounds * std::max(0.213 * (NT + NT2) + 1.0, 8.0);
+            const double cost = rounds * std::max(0.213 * (NT + NT2) + 1.0, 4.5 + 0.2 * (C - 2));
             if (cost < best - 1e-9) { best = cost; s->laC = C; s->NT = NT; s->NT2 = NT2; s->n_pad = 16 * tiles * C; }
           }
           if (best >= 1e300) { delete s; return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead geometry for this n"); }
-          // Who exchanges the partial S': the recurrence wave at the start of its chain (period = chain + exchange, 5.5 us), or
-          // the helper wave a block ahead (its own staging + exchange, ~6 us, but off the chain's path).  The second pays once
-          // the matrix waves' phase is the longer one -- measured: n = 1500 (16 tiles per SIMD) 70.8 vs 78.9 ms, n = 2500 (18)
-          // 136.1 vs 134.4, n = 5000 (21) 236.1 vs 225.2.  (AQ_LA_XHELPER=0/1 pins it: test hook.)
-          s->la_xhelper = (s->NT + s->NT2 >= 18) ? 1 : 0;
-          if (const char *e = getenv("AQ_LA_XHELPER")) s->la_xhelper = atoi(e) != 0;
+          // Who exchanges the partial S': the recurrence wave at the start of its chain.  The helper wave can do it a block ahead
+          // (AQ_LA_XHELPER=1); that paid at n = 5000 while an exchange was three trips through the shared cache (236 vs 225 ms),
+          // with self-validating words it no longer does (222.5 vs 222.0; n = 1500: 58.3 vs 64.5).
+          s->la_xhelper = 0;
         }
+        if (const char *e = getenv("AQ_LA_XHELPER")) s->la_xhelper = atoi(e) != 0;   // test hook
         if (s->TT == 2) s->stagger = (s->NT + 2) / 3;
       }
       if (const char *e = getenv("AQ_STAGGER")) s->stagger = atoi(e) >= 0 ? atoi(e) : 0;
