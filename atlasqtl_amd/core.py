@@ -482,8 +482,8 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbo
     rank passes its own trait columns and shr_fac_inv = q of the whole problem.  trait_offset = global index of
     this rank's first trait: required with a process group when the p x q initial values are drawn on the device
     (the Philox counters are (SNP, global trait), so a sharded run reproduces the single-GPU draws)."""
-    if df not in (1, 3):
-        raise NotImplementedError("df must be 1 or 3 (other odd df: compute_integral_hs_, R/utils.R:425-568, not built)")
+    if df not in (1, 3, 5, 7):
+        raise NotImplementedError("df must be 1, 3, 5 or 7 (compute_integral_hs_, R/utils.R:425-568, is unstable from df = 9 on)")
     if batch != "y":
         raise ValueError("Batch scheme not defined. Exit.")            # :231
     if trace_path is not None:

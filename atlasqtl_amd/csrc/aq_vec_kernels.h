@@ -471,9 +471,12 @@ __global__ void aq_k_pvec_finish(AqPvec v, AqScalars *sc, double c, double c_s, 
         Q = aq_lentz_finish(&s, L);                                                  // R/utils.R:419
       }
       v.Q[j] = Q;
-      if (v.df == 3.0)                                                               // :258 (L is L / df here, :241)
+      if (v.df == 3.0) {                                                             // :258 (L is L / df here, :241)
         lam = exp(-1.0986122886681098 /* log 3 */ - log(L) + log(1.0 - L * Q) - log(Q * (1.0 + L) - 1.0)) - 1.0 / 3.0;
-      else
+      } else if (v.df > 3.0) {                                                       // :260-272 (df = 5, 7)
+        const int ex = ((int)v.df + 1) / 2;
+        lam = exp(log(aq_hs_integral(v.df, L * v.df, ex, ex, Q)) - log(aq_hs_integral(v.df, L * v.df, ex, ex - 1, Q)));
+      } else
         lam = 1.0 / (Q * L) - 1.0;                                                   // :254
     }
     v.lam2_inv[j] = lam;
@@ -613,10 +616,15 @@ __global__ void aq_k_elbo_C(AqPvec v, AqScalars *sc) {
   for (int j = threadIdx.x; j < v.p; j += blockDim.x) {
     double th = v.theta[j], s2 = v.sig2_theta[j], lam = v.lam2_inv[j], L = v.L[j];
     const double quad = log_sig02p / 2 - sig02p * lam * (th * th + s2 - 2 * v.m0 * th + v.m0 * v.m0) / 2 + (log(s2) + 1) / 2;
-    if (v.df == 3.0)   // R/elbo.R:95-105: log(6) + log(3)/2 - log(pi) - log_B + df L lam + ..., log_B = log(9) - log(Q (1 + L) - 1)
+    if (v.df == 3.0) {   // R/elbo.R:95-105: log(6) + log(3)/2 - log(pi) - log_B + df L lam + ..., log_B = log(9) - log(Q (1 + L) - 1)
       acc += quad + 1.791759469228055 + 0.5493061443340549 - 1.1447298858494001741434273513531
              - (2.1972245773362196 - log(v.Q[j] * (1.0 + L) - 1.0)) + 3.0 * L * lam;
-    else
+    } else if (v.df > 3.0) {   // R/elbo.R:107-124: -log(pi)/2 - lgamma(df/2) + df log(df)/2 + lfactorial((df-1)/2) - log_B + df L lam + ...
+      const int ex = ((int)v.df + 1) / 2;
+      const double log_B = -log(aq_hs_integral(v.df, L * v.df, ex, ex - 1, v.Q[j]));
+      acc += quad - 0.5 * 1.1447298858494001741434273513531 - lgamma(v.df / 2) + v.df * log(v.df) / 2 + lgamma((v.df - 1) / 2 + 1.0)
+             - log_B + v.df * L * lam;
+    } else
       acc += quad - 1.1447298858494001741434273513531 /* log(pi) */ + L * lam + log(v.Q[j]);
   }
   acc = aq_block_sum_1024(acc, sh);

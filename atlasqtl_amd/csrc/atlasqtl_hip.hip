@@ -407,10 +407,10 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   if (pr->world_size < 1) return aq_fail(AQ_ERR_ARG, "world_size must be >= 1");
   if (pr->scheme != 0 && pr->scheme != 1) return aq_fail(AQ_ERR_ARG, "scheme must be 0 (global-local horseshoe) or 1 (global-only)");
   const int df = pr->df == 0 ? 1 : pr->df;
-  if (pr->scheme == 0 && df != 1 && df != 3)
-    return aq_fail(AQ_ERR_UNSUPPORTED, "df must be 1 or 3 (other odd df need compute_integral_hs_, R/utils.R:425-568: not built)");
-  if (pr->scheme == 0 && df == 3 && pr->has_anneal)
-    return aq_fail(AQ_ERR_UNSUPPORTED, "df = 3 with annealing needs Kummer's 1F1 in update_annealed_lam2_inv_vb_ (R/update_vb.R:76-81): not built");
+  if (pr->scheme == 0 && df != 1 && df != 3 && df != 5 && df != 7)
+    return aq_fail(AQ_ERR_UNSUPPORTED, "df must be 1, 3, 5 or 7 (the reference calls compute_integral_hs_ unstable from df = 9 on, R/utils.R:510)");
+  if (pr->scheme == 0 && df != 1 && pr->has_anneal)
+    return aq_fail(AQ_ERR_UNSUPPORTED, "df > 1 with annealing needs Kummer's 1F1 in update_annealed_lam2_inv_vb_ (R/update_vb.R:76-81): not built");
   AQ_TRY(aq_need_device(pr->device));
 
   // X must be complete; Y may hold NaN.  With xy_on_device both are device pointers: X is trusted to be the standardised
@@ -1475,13 +1475,19 @@ __host__ __device__ static inline bool aq_special_one(int which, double x, doubl
     case 11: aq_probit_A_imr(x, &a_, &b_, &c_, &d_); *out = b_; return true;
     case 12: aq_probit_A_imr(x, &a_, &b_, &c_, &d_); *out = c_; return true;
     case 13: *out = aq_sigmoid_neg_fast(x); return true;
+    // compute_integral_hs_(alpha = df, beta = L df, m, n, Q(L)) for the horseshoe's df = 5 (14: m = n = 3, 15: m = 3, n = 2) and
+    // df = 7 (16: m = n = 4, 17: m = 4, n = 3); x = L, x2 = Q_approx(L)
+    case 14: *out = aq_hs_integral(5.0, 5.0 * x, 3, 3, x2); return true;
+    case 15: *out = aq_hs_integral(5.0, 5.0 * x, 3, 2, x2); return true;
+    case 16: *out = aq_hs_integral(7.0, 7.0 * x, 4, 4, x2); return true;
+    case 17: *out = aq_hs_integral(7.0, 7.0 * x, 4, 3, x2); return true;
     default: return false;
   }
 }
 
 extern "C" int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len) {
   if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval: bad argument");
-  if (which == 3 && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
+  if ((which == 3 || which >= 14) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
   for (int64_t i = 0; i < len; i++)
     if (!aq_special_one(which, x[i], x2 ? x2[i] : 0.0, &out[i])) return aq_fail(AQ_ERR_ARG, "aq_special_eval: unknown function id");
   return AQ_OK;
@@ -1494,8 +1500,8 @@ __global__ void aq_k_special_eval(int which, const double *x, const double *x2, 
 
 extern "C" int aq_special_eval_device(int32_t which, const double *x, const double *x2, double *out, int64_t len, int32_t device) {
   if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: bad argument");
-  if (which < 0 || which > 13) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: unknown function id");
-  if (which == 3 && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: x2 required");
+  if (which < 0 || which > 17) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: unknown function id");
+  if ((which == 3 || which >= 14) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: x2 required");
   AQ_TRY(aq_need_device(device));
   if (len == 0) return AQ_OK;
   double *dx = nullptr, *dx2 = nullptr, *dout = nullptr;

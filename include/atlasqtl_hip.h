@@ -119,7 +119,8 @@ typedef struct aq_vb_problem {
                                   standardised and NaN-free without a host pass; bit 1: Y is a DEVICE pointer (aq_prep_y_device) */
   /* SURVEY 8f N4 -- the other drivers over the same sweep:
    *   scheme 0  atlasqtl_global_local_core_ (horseshoe, R/atlasqtl_global_local_core.R); df = 0 or 1: half-Cauchy local scales;
-   *             df = 3 (R/atlasqtl_global_local_core.R:258, R/elbo.R:95-105) without annealing
+   *             df = 3 (R/atlasqtl_global_local_core.R:258, R/elbo.R:95-105) and df = 5, 7 (compute_integral_hs_, R/utils.R:425-568;
+   *             :260-272, R/elbo.R:107-124) without annealing; other df: AQ_ERR_UNSUPPORTED
    *   scheme 1  atlasqtl_global_core_ (one global scale, R/atlasqtl_global_core.R:117-320); sig2_theta_vb of list_init and
    *             A2_inv are not used there                                                                               */
   int32_t scheme;

@@ -363,14 +363,75 @@ def e_tau_(eta, eta_vb, kappa, kappa_vb, log_tau_vb, tau_vb):                   
                         + eta * np.log(kappa) - eta_vb * np.log(kappa_vb) - sp.gammaln(eta) + sp.gammaln(eta_vb)))
 
 
+def log_sum_exp_(x):                                                                   # R/utils.R:194-203
+    x = np.asarray(x, dtype=float)
+    offset = np.min(x) if np.max(np.abs(x)) > np.max(x) else np.max(x)
+    return float(np.log(np.sum(np.exp(x - offset))) + offset)
+
+
+def _lfactorial(k):
+    return float(sp.gammaln(k + 1.0))
+
+
+def compute_integral_hs_(alpha, beta, m, n, Q_ab):                                     # R/utils.R:425-568
+    """int_0^inf x^n (1 + alpha x)^(-m) exp(-beta x) dx for m = n or m = n + 1 as the reference writes it out (n = 0 is
+    never passed).  Restated for the cases the driver reaches with df in {5, 7}: m = n in {1, 2, 3, 4} (:434-476) and m = n + 1
+    (:512-560); the general m = n branch (n >= 5, :478-506) is only reached from df >= 9, which the reference itself calls
+    unstable (:510) -- not restated."""
+    la, lb, lQ = np.log(alpha), np.log(beta), np.log(Q_ab)
+    if m == n:
+        out = alpha ** (-n) * beta ** (-1)                                                # :436
+        if n == 1:
+            return out - alpha ** (-2) * Q_ab                                             # :440
+        if n == 2:
+            return out - 2 * alpha ** (-3) * Q_ab + alpha ** (-3) - alpha ** (-4) * beta * Q_ab   # :444
+        if n == 3:                                                                        # :446-458
+            v1 = [-3 * la - lb, np.log(3) - 4 * la, -5 * la - np.log(2) + lb]
+            v2 = [np.log(3) - 4 * la + lQ, np.log(3) - 5 * la + lb + lQ, -4 * la - np.log(2),
+                  -6 * la - np.log(2) + 2 * lb + lQ]
+            return np.exp(log_sum_exp_(v1)) - np.exp(log_sum_exp_(v2))
+        if n == 4:                                                                        # :460-474
+            v1 = [-4 * la - lb, np.log(4) - 5 * la, np.log(2) - 5 * la, np.log(2) - 7 * la + 2 * lb + lQ,
+                  -7 * la - np.log(6) + 2 * lb, -5 * la - np.log(3)]
+            v2 = [np.log(4) - 5 * la + lQ, np.log(4) - 6 * la + lb + lQ, np.log(2) - 7 * la + lb, -6 * la - np.log(6) + lb]
+            return np.exp(log_sum_exp_(v1)) - np.exp(log_sum_exp_(v2))
+        raise NotImplementedError("compute_integral_hs_: m = n >= 5 (df >= 9) is not restated")
+    if m == n + 1:
+        if n == 1:
+            return alpha ** (-2) * Q_ab - alpha ** (-2) + alpha ** (-3) * beta * Q_ab     # :514
+        if n == 2:                                                                        # :516-530
+            v1 = [-3 * la + lQ, -3 * la - np.log(2), -5 * la - np.log(2) + 2 * lb + lQ, -4 * la + np.log(2) + lb + lQ]
+            v2 = [-4 * la - np.log(2) + lb, -3 * la + np.log(2)]
+            return np.exp(log_sum_exp_(v1)) - np.exp(log_sum_exp_(v2))
+        v1 = [-(n + 1) * la + lQ]                                                         # :535-549
+        v1 += [-(2 * n + 1) * la - _lfactorial(n) + _lfactorial(j - 1) + (n - j) * lb + j * la for j in range(2, n + 1, 2)]
+        v1 += [-(2 * n + 1) * la - _lfactorial(n) + n * lb + lQ]
+        v1 += [-n * la + np.log(n) - (1 + k) * la - _lfactorial(k) + _lfactorial(j - 1) + (k - j) * lb + j * la
+               for k in range(2, n) for j in range(2, k + 1, 2)]
+        v1 += [-n * la + np.log(n) - (1 + k) * la - _lfactorial(k) + k * lb + lQ for k in range(1, n)]
+        v2 = [-(2 * n + 1) * la - _lfactorial(n) + _lfactorial(j - 1) + (n - j) * lb + j * la for j in range(1, n + 1, 2)]   # :552-560
+        v2 += [-n * la + np.log(n) - (1 + k) * la - _lfactorial(k) + _lfactorial(j - 1) + (k - j) * lb + j * la
+               for k in range(1, n) for j in range(1, k + 1, 2)]
+        return np.exp(log_sum_exp_(v1)) - np.exp(log_sum_exp_(v2))
+    raise ValueError("Invalid value of m, must be n or n + 1.")                           # :564
+
+
 def e_theta_hs_(lam2_inv_vb, L_vb, log_sig02_inv_vb, m0, theta_vb, Q_app, sig02_inv_vb, sig2_theta_vb, df=1):
     if df == 1:                                                                       # R/elbo.R:85-92
         return float(np.sum(log_sig02_inv_vb / 2 - sig02_inv_vb * lam2_inv_vb
                             * (theta_vb ** 2 + sig2_theta_vb - 2 * m0 * theta_vb + m0 ** 2) / 2
                             + (np.log(sig2_theta_vb) + 1) / 2 - np.log(np.pi) + L_vb * lam2_inv_vb + np.log(Q_app)))
-    assert df == 3                                                                    # R/elbo.R:95-105 (L_vb is L / df)
-    log_B = np.log(9) - np.log(Q_app * (1 + L_vb) - 1)
-    return float(np.sum(np.log(6) + np.log(3) / 2 - np.log(np.pi) - log_B + df * L_vb * lam2_inv_vb
+    if df == 3:                                                                       # R/elbo.R:95-105 (L_vb is L / df)
+        log_B = np.log(9) - np.log(Q_app * (1 + L_vb) - 1)
+        return float(np.sum(np.log(6) + np.log(3) / 2 - np.log(np.pi) - log_B + df * L_vb * lam2_inv_vb
+                            + log_sig02_inv_vb / 2 - sig02_inv_vb * lam2_inv_vb
+                            * (theta_vb ** 2 + sig2_theta_vb - 2 * m0 * theta_vb + m0 ** 2) / 2
+                            + (np.log(sig2_theta_vb) + 1) / 2))
+    exponent = (df + 1) // 2                                                          # R/elbo.R:107-124 (any odd df)
+    log_B = -np.log(np.array([compute_integral_hs_(df, L_vb[j] * df, exponent, exponent - 1, Q_app[j])
+                              for j in range(len(lam2_inv_vb))]))
+    return float(np.sum(-np.log(np.pi) / 2 - sp.gammaln(df / 2) + df * np.log(df) / 2 + _lfactorial((df - 1) // 2)
+                        - log_B + df * L_vb * lam2_inv_vb
                         + log_sig02_inv_vb / 2 - sig02_inv_vb * lam2_inv_vb
                         * (theta_vb ** 2 + sig2_theta_vb - 2 * m0 * theta_vb + m0 ** 2) / 2
                         + (np.log(sig2_theta_vb) + 1) / 2))
@@ -482,7 +543,7 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_
     X = _F(X)
     n, p = X.shape
     q = Y.shape[1]
-    assert df in (1, 3) and scheme in ("global_local", "global")
+    assert df in (1, 3, 5, 7) and scheme in ("global_local", "global")
     assert df == 1 or anneal is None
 
     if np.isnan(Y).any():                                                             # :19-32
@@ -610,9 +671,15 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_
                 Q_app, lentz_iters = Q_approx_vec(L_vb, return_iters=True)
                 if df == 1:
                     lam2_inv_vb = 1 / (Q_app * L_vb) - 1                                # :254
-                else:                                                                 # df == 3, :258
+                elif df == 3:                                                         # :258
                     lam2_inv_vb = np.exp(-np.log(3) - np.log(L_vb) + np.log(1 - L_vb * Q_app)
                                          - np.log(Q_app * (1 + L_vb) - 1)) - 1 / 3
+                else:                                                                 # :260-272
+                    exponent = (df + 1) // 2
+                    lam2_inv_vb = np.array([
+                        np.exp(np.log(compute_integral_hs_(df, L_vb[j] * df, exponent, exponent, Q_app[j]))
+                               - np.log(compute_integral_hs_(df, L_vb[j] * df, exponent, exponent - 1, Q_app[j])))
+                        for j in range(p)])
             xi_inv_vb = nu_xi_inv_vb / rho_xi_inv_vb                                      # :276
             sig2_theta_vb = update_sig2_c0_vb_(q, 1 / (sig02_inv_vb * lam2_inv_vb * shr_fac_inv), c=c)   # :278
             theta_vb = update_theta_vb_(Z, m0, sig02_inv_vb * lam2_inv_vb * shr_fac_inv, sig2_theta_vb,

@@ -1,7 +1,8 @@
 """GPU: the other drivers over the same sweep against the oracle's restatements:
   * the global-only core atlasqtl_global_core_ (R/atlasqtl_global_core.R:117-320, ELBO :372-421), with and without annealing,
     complete and incomplete Y;
-  * the horseshoe with df = 3 (R/atlasqtl_global_local_core.R:258, R/elbo.R:95-105), without annealing."""
+  * the horseshoe with df = 3 (R/atlasqtl_global_local_core.R:258, R/elbo.R:95-105) and with df = 5, 7 (compute_integral_hs_,
+    R/utils.R:425-568; R/atlasqtl_global_local_core.R:260-272, R/elbo.R:107-124), without annealing."""
 import numpy as np
 import pytest
 
@@ -40,15 +41,16 @@ def test_global_only_core_matches_oracle(shape, na, anneal):
 
 
 @pytest.mark.parametrize("shape,na", [((100, 75, 20), 0.0), ((300, 130, 49), 0.0), ((200, 90, 33), 0.08), ((1000, 208, 40), 0.0)])
-def test_horseshoe_df3_matches_oracle(shape, na):
+@pytest.mark.parametrize("df", [3, 5, 7])
+def test_horseshoe_df_3_5_7_matches_oracle(shape, na, df):
     import atlasqtl_amd as A
     from oracle import atlasqtl_oracle as O
     n, p, q = shape
     prob = make_problem(n, p, q, p_act=8, prob_assoc=1.0 if q <= 20 else 0.3, na_frac=na)
     tr = []
-    ref = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, None, 3, 0.1, 1000, prob["list_hyper"], prob["list_init"], trace=tr,
+    ref = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, None, df, 0.1, 1000, prob["list_hyper"], prob["list_init"], trace=tr,
                                         full_output=True)
-    got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, None, 3, 0.1, 1000, 0, prob["list_hyper"], prob["list_init"],
+    got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, None, df, 0.1, 1000, 0, prob["list_hyper"], prob["list_init"],
                                         full_output=True, debug=True)
     _compare(ref, got, tr)
     np.testing.assert_allclose(got["lam2_inv_vb"], ref["lam2_inv_vb"], rtol=1e-6)
@@ -60,5 +62,7 @@ def test_unsupported_variants_fail_loudly():
     prob = make_problem(100, 40, 8, p_act=4, prob_assoc=1.0)
     with pytest.raises(AtlasqtlHipError, match="Kummer"):
         A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 8, (1, 2, 10), 3, 0.1, 10, 0, prob["list_hyper"], prob["list_init"])
-    with pytest.raises(NotImplementedError, match="df must be 1 or 3"):
-        A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 8, None, 5, 0.1, 10, 0, prob["list_hyper"], prob["list_init"])
+    with pytest.raises(AtlasqtlHipError, match="Kummer"):
+        A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 8, (1, 2, 10), 5, 0.1, 10, 0, prob["list_hyper"], prob["list_init"])
+    with pytest.raises(NotImplementedError, match="df must be 1, 3, 5 or 7"):
+        A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 8, None, 9, 0.1, 10, 0, prob["list_hyper"], prob["list_init"])

@@ -181,3 +181,31 @@ def test_philox4x32_10_known_answers():
     g2, m2 = O.philox_init(12345, 400, 10, -2.0, 0.3, trait_offset=20)        # a shard reproduces its own columns
     np.testing.assert_array_equal(g2, gam[:, 20:])
     np.testing.assert_array_equal(m2, mu[:, 20:])
+
+
+def test_compute_integral_hs_against_quadrature():
+    """compute_integral_hs_ (R/utils.R:425-568), the closed forms behind df >= 5 of the horseshoe, restated in the
+    oracle term by term and compared with numerical quadrature of int x^n (1 + a x)^-m exp(-b x) dx -- evidence about the
+    REFERENCE's formulas, independent of any restatement of ours:
+      * df = 5 (m = n = 3; m = 3, n = 2) and the m = 4, n = 3 list of df = 7 are right; they are differences of large terms, so
+        digits go as L = b / a grows (the reference's own remark at :510);
+      * the n = m = 4 list (:460-474, df = 7's numerator) does NOT add up to the integral, not even for small L.
+    The device path reproduces the lists as written (parity with the reference is the contract), bugs included."""
+    from scipy import integrate, special
+    from oracle import atlasqtl_oracle as O
+    err = {}
+    for df in (3, 5, 7):
+        e = (df + 1) // 2
+        for L in (1e-3, 1e-2, 0.1, 0.5, 1.0, 3.0, 100.0):
+            alpha, beta = float(df), L * df
+            Q = float(np.exp(L) * special.exp1(L))
+            for (m, n) in ((e, e), (e, e - 1)):
+                ref, _ = integrate.quad(lambda x: x ** n * (1 + alpha * x) ** (-m) * np.exp(-beta * x), 0, np.inf,
+                                        epsabs=0, epsrel=1e-12, limit=400)
+                err[(df, m, n, L)] = abs(O.compute_integral_hs_(alpha, beta, m, n, Q) - ref) / abs(ref)
+    for (df, m, n, L), v in err.items():
+        if (m, n) == (4, 4):
+            assert v > 1e-4, (df, m, n, L, v)                  # the reference's n = 4 list is not the integral
+        elif L <= 3.0:
+            assert v < 1e-10, (df, m, n, L, v)                 # right where the cancellation is mild
+    assert err[(5, 3, 3, 100.0)] > 1e-9 and err[(7, 4, 3, 100.0)] > 1e-9      # digits lost at large L

@@ -127,3 +127,13 @@ def test_q_approx_vec_shared_stopping_rule():
         assert L.aq_q_approx_vec(_lib.as_dp(np.ascontiguousarray(x)), _lib.as_dp(out), x.size, C.byref(it)) == 0
         assert it.value == iters_ref
         assert np.max(np.abs(out - ref) / ref) < 1e-13
+
+
+def test_hs_integral_matches_the_oracle_restatement():
+    """aq_hs_integral (compute_integral_hs_, R/utils.R:425-568, the four (m, n) of df = 5 and 7; term lists written out by hand
+    for the device) against the oracle's restatement with the reference's generic loops, where the lists are well conditioned."""
+    x = 10 ** np.random.default_rng(5).uniform(-3, 0.7, 300)                  # L = beta / alpha
+    Q = np.exp(x) * sp.exp1(x)
+    for which, (df, m, n) in {14: (5, 3, 3), 15: (5, 3, 2), 16: (7, 4, 4), 17: (7, 4, 3)}.items():
+        ref = np.array([O.compute_integral_hs_(float(df), xi * df, m, n, qi) for xi, qi in zip(x, Q)])
+        assert np.max(np.abs(ev(which, x, Q) - ref) / np.abs(ref)) < 1e-11, which
