@@ -1,7 +1,7 @@
 """Developer check: error magnitudes vs the oracle and timings at larger sizes (GPU box)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests.util import make_problem
 import atlasqtl_amd as A
 from atlasqtl_amd.core import VbRun

@@ -1,11 +1,11 @@
 """Randomised parity sweep: random small shapes (ragged n, p, q; with and without missing values; with and without
-annealing) through the HIP path against the oracle.  usage: python tools/fuzz_parity.py [ncases] [seed]
+annealing) through the HIP path against the oracle.  usage: python tests/tools/fuzz_parity.py [ncases] [seed]
 (AQ_FUZZ_NMAX / AQ_FUZZ_PMAX / AQ_FUZZ_QMAX widen the shape ranges, e.g. AQ_FUZZ_NMAX=1300 crosses the sample-split boundary)"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 import atlasqtl_amd as A
