@@ -318,17 +318,24 @@ __global__ void aq_k_qpre(AqQvec v, AqScalars *sc, double c) {
 // ------------------------------------------------------------ reductions ----
 // red[j] = sum over tiles of rowA + rowGB (fixed order) = rowSums(Z), R/update_vb.R:179
 // rowGB holds gb_rows rows per tile (the generic kernel splits a tile over several workgroups), rowA one.
-__global__ void aq_k_reduce_rows(const double *__restrict__ rowA, const double *__restrict__ rowGB,
-                                 double *__restrict__ red, int ntile, int p_pad, int gb_rows) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= p_pad) return;
+// Workgroup = 64 predictors x 4 interleaved quarters of the tiles (one thread per predictor left the GPU three quarters empty and
+// every thread waiting on its own 625 loads: 0.27 ms at C3); the four partial sums are added in fixed order.
+__global__ __launch_bounds__(256) void aq_k_reduce_rows(const double *__restrict__ rowA, const double *__restrict__ rowGB,
+                                                        double *__restrict__ red, int ntile, int p_pad, int gb_rows) {
+  __shared__ double part[4][64];
+  const int jl = threadIdx.x & 63, c = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jl;
   double s = 0.0;
-  for (int t = 0; t < ntile; t++) {
-    double gb = rowGB[(size_t)t * gb_rows * p_pad + j];
-    for (int r = 1; r < gb_rows; r++) gb += rowGB[((size_t)t * gb_rows + r) * p_pad + j];
-    s += (rowA ? rowA[(size_t)t * p_pad + j] : 0.0) + gb;   // rowA == NULL: the sweep kernel already folded a into rowGB
+  if (j < p_pad) {
+    for (int t = c; t < ntile; t += 4) {
+      double gb = rowGB[(size_t)t * gb_rows * p_pad + j];
+      for (int r = 1; r < gb_rows; r++) gb += rowGB[((size_t)t * gb_rows + r) * p_pad + j];
+      s += (rowA ? rowA[(size_t)t * p_pad + j] : 0.0) + gb;   // rowA == NULL: the sweep kernel already folded a into rowGB
+    }
   }
-  red[j] = s;
+  part[c][jl] = s;
+  __syncthreads();
+  if (c == 0 && j < p_pad) red[j] = ((part[0][jl] + part[1][jl]) + part[2][jl]) + part[3][jl];
 }
 
 // sums[0] <- column sums added over the chained SNP-segment slots (fixed order); ||R||^2 is the last segment's.

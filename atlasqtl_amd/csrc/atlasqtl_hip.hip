@@ -880,7 +880,7 @@ static int aq_sweep_part_a(aq_vb *s) {
   s->pre_done = false;
   hipLaunchKernelGGL(aq_k_qpre, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, qv, s->sc, s->c);
   AQ_TRY(aq_launch_core(s, 0, s->c));
-  hipLaunchKernelGGL(aq_k_reduce_rows, dim3((s->p_pad + 255) / 256), dim3(256), 0, 0, s->fused ? (const double *)nullptr : s->rowA, s->rowGB,
+  hipLaunchKernelGGL(aq_k_reduce_rows, dim3((s->p_pad + 63) / 64), dim3(256), 0, 0, s->fused ? (const double *)nullptr : s->rowA, s->rowGB,
                      s->red, s->ntile, s->p_pad, s->WPT);
   hipLaunchKernelGGL(aq_k_reduce_q_scalars, dim3(1), dim3(1024), 0, 0, qv, s->red + s->p_pad);
   AQ_HIP(hipGetLastError());
