@@ -56,11 +56,16 @@ __device__ __forceinline__ double aq_row16_sum(double v) {
   return v;
 }
 
+// cache policy of the Gram-block stream (49 KB per phase and workgroup, read once per sweep): 2 = nt, non-temporal, so that it
+// does not push the X operand panels -- which every workgroup of the XCD re-reads -- out of the L2
+#ifndef AQ_GLDS_AUX
+#define AQ_GLDS_AUX 2
+#endif
 // One LDS-DMA transfer (global_load_lds_dwordx4): 64 lanes x 16 B from per-lane global addresses to lds_base + 16 lane, with
 // no VGPR destination; completion is counted in vmcnt.  lds_base must be wave-uniform.
 __device__ __forceinline__ void aq_glds16(const void *gsrc_lane, void *lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
-                                   (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void *)lds_base, 16, 0, AQ_GLDS_AUX);
 }
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The residual tiles live in
