@@ -49,7 +49,8 @@ class AqVbStatus(C.Structure):
         ("it", C.c_int32), ("converged", C.c_int32), ("lb_opt", C.c_double), ("diff_lb", C.c_double),
         ("c", C.c_double), ("annealing", C.c_int32), ("n_elbo", C.c_int32), ("core_ms", C.c_double),
         ("core_launches", C.c_int32), ("sig02_inv_vb", C.c_double), ("sig2_inv_vb", C.c_double),
-        ("lentz_iters", C.c_int32), ("core_kernel", C.c_int32),
+        ("lentz_iters", C.c_int32), ("core_kernel", C.c_int32), ("split_parts", C.c_int32),
+        ("tiles_per_group", C.c_int32), ("chain_segments", C.c_int32),
     ]
 
 

@@ -1297,6 +1297,9 @@ extern "C" int aq_vb_get_status(aq_vb_handle s, aq_vb_status *st) {
   st->sig2_inv_vb = h.sig2_inv;
   st->lentz_iters = h.lentz_iters;
   st->core_kernel = aq_core_kernel_id(s);
+  st->split_parts = s->use_la ? s->laC : s->use_mis ? s->misC : 1;
+  st->tiles_per_group = s->use_la ? s->TT : 1;
+  st->chain_segments = s->chain > 1 ? s->chain : 0;
   return AQ_OK;
 }
 

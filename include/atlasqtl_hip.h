@@ -170,8 +170,11 @@ typedef struct aq_vb_status {
   int32_t core_launches;
   double sig02_inv_vb, sig2_inv_vb;
   int32_t lentz_iters;   /* shared Lentz iteration count of the last non-annealed sweep */
-  int32_t core_kernel;   /* which core sweep kernel this handle runs: 0 look-ahead MFMA (complete Y, n <= 1056),
-                            2 generic wave-per-trait (VALU), 3 masked MFMA (missing values in Y, or n > 1056) */
+  int32_t core_kernel;   /* which core sweep kernel this handle runs: 0 look-ahead MFMA (complete Y, or Y with NA when the
+                            traits' own Gram blocks fit in HBM), 2 generic wave-per-trait (VALU), 3 round-1 masked MFMA */
+  int32_t split_parts;   /* launch plan of the core kernel: workgroups sharing one trait group along the samples (1 = none), */
+  int32_t tiles_per_group;   /* 16-trait tiles per workgroup (1 or 2),                                                  */
+  int32_t chain_segments;    /* chained SNP segments per trait group (0 = none)                                         */
 } aq_vb_status;
 int aq_vb_get_status(aq_vb_handle h, aq_vb_status *st);
 

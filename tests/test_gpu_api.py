@@ -316,3 +316,24 @@ def test_atlasqtl_with_device_init_converges():
     assert vb.converged is True
     top = set(np.argsort(-vb.gam_vb.sum(1))[:6])
     assert len(top & set(d["act_x"])) >= 4
+
+
+def test_launch_plan_follows_the_problem_shape(monkeypatch):
+    """aq_vb_status reports the launch plan of the core kernel.  Few trait groups and a long sample axis: the idle CUs share the
+    samples (two workgroups per group); a short sample axis (the chain is the bound, a split only adds the exchange), Y with
+    missing values, or AQ_LA_NOSPLIT=1: one workgroup per group; n beyond one workgroup's registers: always split."""
+    from tests.util import make_problem
+
+    def plan(n, p, q, **kw):
+        run = _vbrun(make_problem(n, p, q, p_act=4, prob_assoc=0.5, **kw))
+        st = run.status()
+        run.close()
+        return st["core_kernel"], st["split_parts"], st["tiles_per_group"], st["chain_segments"]
+
+    assert plan(1000, 64, 24) == (0, 2, 1, 0)
+    assert plan(200, 64, 24) == (0, 1, 1, 0)
+    assert plan(1000, 64, 24, na_frac=0.05) == (0, 1, 1, 0)
+    k, parts, tiles, chain = plan(2500, 40, 20)
+    assert (k, tiles, chain) == (0, 1, 0) and parts >= 2
+    monkeypatch.setenv("AQ_LA_NOSPLIT", "1")
+    assert plan(1000, 64, 24) == (0, 1, 1, 0)
