@@ -296,7 +296,9 @@ def main():
                        "elbo_evals_in_timed_region": st1["n_elbo"] - st0["n_elbo"], "elbo_last": st1["lb_opt"],
                        # the warm-up sweeps are the annealing ladder (the probit terms are evaluated twice there)
                        "annealed_sweeps_per_s": (args.warmup / t_warm) if t_warm else None,
-                       "setup_s": round(t_setup, 1)},
+                       "setup_s": round(t_setup, 1),
+                       # the host's launch plan of the core kernel on rank 0 (aq_vb_status)
+                       "launch": {k: st1[k] for k in ("core_kernel", "split_parts", "tiles_per_group", "chain_segments")}},
             "roofline": {"bound": "mfma", "kernel": {0: "aq_core_sweep_la_kernel", 2: "aq_trait_wave_kernel",
                                                      3: "aq_core_sweep_mis_kernel"}[st1["core_kernel"]], "achieved": achieved,
                          "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,
