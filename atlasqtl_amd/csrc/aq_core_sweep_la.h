@@ -10,8 +10,9 @@
 //       1 "recurrence" wave (wave 3; lane = (row group, trait): 4 / TT groups of 16 TT traits),
 //       1 "helper" wave (wave 7, same SIMD as wave 3): stages gam, mu, the Gram blocks and the probit terms of the next
 //         SNP block, finalises the previous one (stores, column / row sums).
-//     No f64 MFMA is ever issued on the recurrence wave's SIMD: fp64 VALU work and f64 MFMAs share one datapath and the
-//     chain would wait behind every one of them (measured: 2.6x slower).
+//     fp64 VALU work and f64 MFMAs share one datapath (a chain that has to wait behind MFMAs is 2.6x slower), so all fp64
+//     VALU work lives on SIMD 3.  With two trait tiles per workgroup the recurrence wave also owns NT3 = 3 or 6 residual
+//     tiles (aq_la_nt3) whose matrix work it does BETWEEN two chains -- SIMD 3's MFMA slots would otherwise go unused.
 //   phase b:
 //     recurrence wave : SNP block b.   s_j = S'_b[j] - (X_b'X_{b-1} delta_{b-1})[j]      cross-block Gram, precomputed
 //                                            - sum_{i<j} (X_b'X_b)[j,i] delta_i            in-block Gram
@@ -24,9 +25,9 @@
 // TT = 2 (two trait tiles per workgroup, used when there are enough tiles to fill the chip): every X operand fetched
 // from L2 feeds two MFMAs, the chain is evaluated once for 32 traits (two row groups instead of four: 37 % fewer fp64
 // VALU instructions per trait), and a phase carries twice the matrix work, so the fixed per-phase costs (hand-off
-// counters, delta read, accumulator drain, S' store) weigh half as much.  The phase is then long enough for the two matrix
-// waves of a SIMD to run out of step (waves 4-6 start a phase when their partner is a given number of tiles into it), so that
-// one wave's hand-off gap is covered by the other's MFMAs.
+// counters, delta read, accumulator drain, S' store) weigh half as much.  The two matrix waves of a SIMD run out of step
+// (waves 4-6 start a phase when their partner is a given number of tiles into it: a.stagger); that paid while the matrix
+// SIMDs were the bound, with tiles on the recurrence wave SIMD 3 is co-critical and any stagger 0 .. 9 measures the same.
 //
 // The X operand stream is issued by inline-asm loads with explicit s_waitcnt vmcnt counts: the compiler can neither
 // hoist the loads of a fully unrolled tile loop (which cost 16 VGPRs per residual tile and spilled) nor has it to
