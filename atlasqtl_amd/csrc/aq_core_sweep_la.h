@@ -204,6 +204,15 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   long long dg_wait = 0, dg_wait_b = 0;   // waits on the matrix / recurrence counters; on the helper's and the stagger counters
   const long long dg_t0 = __builtin_readcyclecounter();
 #endif
+#ifdef AQ_DIAG_TIME
+  // timeline of workgroup 0, phases 64 .. 95: slot k of (wave, phase) <- cycle counter (behind the per-wave counters in a.dbg)
+  auto tl_mark = [&](int i, int k) __attribute__((always_inline)) {
+    if (a.dbg && blockIdx.x == 0 && i >= 64 && i < 96 && lane == 0)
+      a.dbg[(size_t)gridDim.x * 24 + ((size_t)w * 32 + (i - 64)) * 4 + k] = __builtin_readcyclecounter();
+  };
+#else
+  auto tl_mark = [&](int, int) __attribute__((always_inline)) {};
+#endif
   auto wait_ge = [&](int idx, int val) __attribute__((always_inline)) {
 #ifdef AQ_DIAG_TIME
     const long long t_in = __builtin_readcyclecounter();
@@ -300,9 +309,12 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       const double mflag = do_u ? -1.0 : 0.0;
       const int bu = seg_b0 + (i >= 2 ? i - 2 : 0), bs = seg_b0 + (i < nblk ? i : nblk - 1);
       const int nbu = seg_b0 + (i >= 1 ? (i - 1 < nblk ? i - 1 : nblk - 1) : 0), nbs = seg_b0 + (i + 1 < nblk ? i + 1 : nblk - 1);
+      tl_mark(i, 0);                     // phase entered (recurrence wave: before its chain)
       hook(i);
+      tl_mark(i, 1);                     // (recurrence wave: chain done)
       if (do_u && (ROLE != 2 || a.mode == 1)) wait_ge(6, i - 1);   // (sweep mode: the recurrence wave wrote that delta itself)
       if (ROLE == 1 && a.stagger) wait_ge(8 + (mw - 3), i + 1);
+      tl_mark(i, 2);                     // waits passed: tile loop starts
       double nd[TT][4];
       {
         // (4 s + g) NTR + 16 tt + col.  The lane id is recomputed here and hidden from the optimiser: kept in a register
@@ -412,6 +424,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           for (int r = 0; r < 4; r++) Sp[ps][slot][(4 * r + g) * NTR + 16 * tt + col] = acc[tt][r];
       }
       signal(ROLE == 2 ? 11 : mw, i + 1);
+      tl_mark(i, 3);                     // S' stored and announced
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(c0), "+v"(c1), "+v"(q0), "+v"(q1), "+v"(d0), "+v"(d1));   // the dangling prefetch
     // ---- write the residual back and ||R_k||^2 partials ----

@@ -319,7 +319,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     a.dbg = nullptr;
     static long long *dbg_buf = nullptr;   // AQ_DIAG_DUMP=<file> with a -DAQ_DIAG_TIME build: per-role wait / total cycles of sweep 15
     const char *dump = getenv("AQ_DIAG_DUMP");
-    const size_t dbg_n = (size_t)32 * nwg * 8 * 3;
+    const size_t dbg_n = (size_t)32 * nwg * 8 * 3 + 8 * 32 * 4;   // per-wave counters of up to 32 nwg workgroups + the timeline of workgroup 0
     if (dump && mode == 0) {
       if (!dbg_buf) AQ_HIP(hipMalloc((void **)&dbg_buf, dbg_n * sizeof(long long)));
       AQ_HIP(hipMemsetAsync(dbg_buf, 0, dbg_n * sizeof(long long), 0));
@@ -346,12 +346,19 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
       hipLaunchKernelGGL(aq_k_sum_parts, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->rnpart, s->sums + (size_t)4 * s->q_pad, s->laC, s->q_pad);
     if (a.dbg && s->it == 15) {
       AQ_HIP(hipDeviceSynchronize());
-      std::vector<long long> h((size_t)grid * 24);
+      std::vector<long long> h((size_t)grid * 24 + 8 * 32 * 4);
       AQ_HIP(hipMemcpy(h.data(), a.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
       if (FILE *f = fopen(dump, "w")) {
         for (unsigned b = 0; b < grid; b++)
           for (int w = 0; w < 8; w++)
             fprintf(f, "%u %d %lld %lld %lld\n", b, w, h[((size_t)b * 8 + w) * 3], h[((size_t)b * 8 + w) * 3 + 1], h[((size_t)b * 8 + w) * 3 + 2]);
+        fclose(f);
+      }
+      if (FILE *f = fopen((std::string(dump) + ".timeline").c_str(), "w")) {   // workgroup 0, phases 64 .. 95: wave, phase, 4 marks
+        const long long *t = h.data() + (size_t)grid * 24;
+        for (int w = 0; w < 8; w++)
+          for (int i = 0; i < 32; i++)
+            fprintf(f, "%d %d %lld %lld %lld %lld\n", w, 64 + i, t[(w * 32 + i) * 4], t[(w * 32 + i) * 4 + 1], t[(w * 32 + i) * 4 + 2], t[(w * 32 + i) * 4 + 3]);
         fclose(f);
       }
     }
