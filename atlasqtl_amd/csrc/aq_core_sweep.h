@@ -58,6 +58,7 @@ struct AqCoreArgs {
   // k*C + part holds the residual rows [part, part + 1) * n_pad / C.  Per SNP block each publishes its partial S' and adds the
   // others' in fixed order before running the SAME chain (bitwise identical delta in all parts)
   int C;                 // parts per trait group (1 = no split)
+  int xtouch;            // helper waves warm the L2 with the next phase's X operand panels (one 128-B line per lane)
   int xhelper;           // sample split: 1 = the helper wave exchanges the partial S' a block ahead, 0 = the recurrence wave at chain start
   double *Pbuf;          // [nwg][2][C][256 TT] partial S' of each part, double-buffered by block parity
   int *pflag;            // [nwg][C] number of blocks whose partial S' this part has published

@@ -312,8 +312,10 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     const unsigned nwg = (unsigned)(s->ntile / s->TT);
     a.done = s->done; a.errflag = s->errflag; a.stagger = s->stagger;
     a.C = s->laC; a.xhelper = s->la_xhelper; a.Pbuf = s->Pbuf; a.pflag = s->pflag; a.rnpart = s->rnpart;
+    a.xtouch = getenv("AQ_XTOUCH") ? atoi(getenv("AQ_XTOUCH")) : 1;   // (AQ_XTOUCH=0: no L2 warm-up by the helper waves)
     a.mis = s->mis; a.GK = s->GK; a.tau = s->tau; a.log_tau = s->log_tau;
     a.sig2_inv_p = &s->sc->sig2_inv; a.log_sig2_inv_p = &s->sc->log_sig2_inv;
+    if (s->laC > 1 && (!a.Pbuf || !a.rnpart || !a.errflag)) return aq_fail(AQ_ERR_DEVICE, "sample split without its exchange buffers");
     if (s->laC > 1 && mode == 0)   // the exchange slots start with tag 0 (aq_core_sweep_la.h, split_exchange)
       AQ_HIP(hipMemsetAsync(s->Pbuf, 0, (size_t)s->ntile * 2 * s->laC * 256 * sizeof(double), 0));
     a.dbg = nullptr;
