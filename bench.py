@@ -37,13 +37,13 @@ PEAK_FP64_MFMA_MEASURED_TFLOPS = 77.8
 # HBM-side bytes of ONE core-sweep launch at the default workload on one GPU, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command with the gfx950
 # correction (FETCH_SIZE x 2 for coalesced streaming reads, calibrated on aq_k_prepass's gam read):
-# profiles/r02_pmc_hbm_traffic_v3.txt (the post-annealing instance <10, 9, true, 2>: reads 2 x 10,602,299 KiB + writes 8,401,049 KiB).
-# PMC counters cannot be read from inside the timed run, so this is the profile's number for the same kernel and workload, not
-# a value measured in this run.
-PMC_TRAFFIC_C3_BYTES = 3.03e10
+# profiles/r02_pmc_hbm_traffic_v4.txt (the post-annealing instance <10, 9, true, 2>: reads 2 x 13,324,838 KiB + writes 8,433,846 KiB;
+# the reads include the helper waves' L2 warm-up touches).  PMC counters cannot be read from inside the timed run, so this is the
+# profile's number for the same kernel and workload, not a value measured in this run.
+PMC_TRAFFIC_C3_BYTES = 3.59e10
 # the same workload with 5 % of Y missing (AQ_BENCH_NA=0.05: the MASK instance of the look-ahead kernel, which streams the
-# traits' own Gram blocks, 98 GB per sweep): profiles/r02_pmc_hbm_traffic_c3_na5_v2.txt (2 x 70,536,564 KiB + 8,769,788 KiB)
-PMC_TRAFFIC_C3_NA5_BYTES = 1.53e11
+# traits' own Gram blocks, 98 GB per sweep): profiles/r02_pmc_hbm_traffic_c3_na5_v3.txt (2 x 75,546,546 KiB + 8,769,803 KiB)
+PMC_TRAFFIC_C3_NA5_BYTES = 1.64e11
 
 
 def build_problem(n, p, q_total, k0, k1, device, seed=123):
