@@ -164,6 +164,8 @@ struct aq_vb {
   int *pflag = nullptr;
   double *Xcm = nullptr, *mis = nullptr, *XN = nullptr;
   int ncu = 256;
+  int la_xtouch = 1;        // helper waves warm the L2 with the next phase's X operand panels (AQ_XTOUCH=0 switches it off)
+  bool la_nt3_pinned = false;   // AQ_NT3 given: the annealed sweeps keep the geometry as well
   int la_xhelper = 0;       // sample split of the look-ahead kernel: exchange on the helper wave (long matrix phases) or on the recurrence wave
   int chain = 0;            // > 1: chained-segment launch with that many SNP segments (aq_core_sweep_la.h, SEG)
   int *done = nullptr, *errflag = nullptr;
@@ -312,7 +314,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     const unsigned nwg = (unsigned)(s->ntile / s->TT);
     a.done = s->done; a.errflag = s->errflag; a.stagger = s->stagger;
     a.C = s->laC; a.xhelper = s->la_xhelper; a.Pbuf = s->Pbuf; a.pflag = s->pflag; a.rnpart = s->rnpart;
-    a.xtouch = getenv("AQ_XTOUCH") ? atoi(getenv("AQ_XTOUCH")) : 1;   // (AQ_XTOUCH=0: no L2 warm-up by the helper waves)
+    a.xtouch = s->la_xtouch;
     a.mis = s->mis; a.GK = s->GK; a.tau = s->tau; a.log_tau = s->log_tau;
     a.sig2_inv_p = &s->sc->sig2_inv; a.log_sig2_inv_p = &s->sc->log_sig2_inv;
     if (s->laC > 1 && (!a.Pbuf || !a.rnpart || !a.errflag)) return aq_fail(AQ_ERR_DEVICE, "sample split without its exchange buffers");
@@ -323,7 +325,13 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     const char *dump = getenv("AQ_DIAG_DUMP");
     const size_t dbg_n = (size_t)32 * nwg * 8 * 3 + 8 * 32 * 4;   // per-wave counters of up to 32 nwg workgroups + the timeline of workgroup 0
     if (dump && mode == 0) {
-      if (!dbg_buf) AQ_HIP(hipMalloc((void **)&dbg_buf, dbg_n * sizeof(long long)));
+      static size_t dbg_cap = 0;
+      if (dbg_n > dbg_cap) {
+        if (dbg_buf) AQ_HIP(hipFree(dbg_buf));
+        dbg_buf = nullptr;
+        AQ_HIP(hipMalloc((void **)&dbg_buf, dbg_n * sizeof(long long)));
+        dbg_cap = dbg_n;
+      }
       AQ_HIP(hipMemsetAsync(dbg_buf, 0, dbg_n * sizeof(long long), 0));
       a.dbg = dbg_buf;
     }
@@ -336,7 +344,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     // at C3), so the recurrence wave gives three of its six residual tiles back to the matrix waves: geometry (NT, NT, 3)
     // instead of (NT, NT - 1, 6) -- the same 6 NT + 3 tiles, hence the same n_pad and residual layout in HBM (38.5 ms).
     int NT2l = s->NT2;
-    if (s->TT == 2 && !a.c_is_one && mode == 0 && s->NT2 == s->NT - 1 && aq_la_nt3(s->NT, s->NT2, 2) == 6 && !getenv("AQ_NT3")) NT2l = s->NT;
+    if (s->TT == 2 && !a.c_is_one && mode == 0 && s->NT2 == s->NT - 1 && aq_la_nt3(s->NT, s->NT2, 2) == 6 && !s->la_nt3_pinned) NT2l = s->NT;
     int lrc = s->la_mask ? aq_la_launch_mask(s->NT, s->NT2, chained, grid, 0, a)
               : s->TT == 2 ? aq_la_launch_tt2(s->NT, NT2l, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
     if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
@@ -596,6 +604,8 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
           s->la_xhelper = 0;
         }
         if (const char *e = getenv("AQ_LA_XHELPER")) s->la_xhelper = atoi(e) != 0;   // test hook
+        if (const char *e = getenv("AQ_XTOUCH")) s->la_xtouch = atoi(e) != 0;
+        s->la_nt3_pinned = getenv("AQ_NT3") != nullptr;
         if (s->TT == 2) s->stagger = (s->NT + 2) / 3;
       }
       if (const char *e = getenv("AQ_STAGGER")) s->stagger = atoi(e) >= 0 ? atoi(e) : 0;
