@@ -108,6 +108,11 @@ __device__ __forceinline__ void aq_static_for(F &&f) {
 // wait until at most N of this wave's vector-memory operations are outstanding; the operands tie the wait to the
 // registers it covers so that no use can be scheduled above it
 #define AQ_WAIT2(N, d0, d1) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(d0), "+v"(d1))
+template <int N>
+__device__ __forceinline__ void aq_wait2n(aq_v2 &d0, aq_v2 &d1) {   // the same with a count computed at compile time
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(d0), "+v"(d1) : "n"(N));
+}
 
 // NT = residual tiles of matrix waves 0,1,2; NT2 (= NT or NT-1) those of waves 4,5,6: each SIMD carries NT + NT2.
 // SEG: chained-segment launch (a.nseg * nwg workgroups).  Workgroup s*nwg + k handles SNP segment s of trait-tile group
@@ -293,6 +298,15 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     const char *XUb = (const char *)a.XU, *XAb = (const char *)a.XA;
     const long long BLK = (long long)NTT * C * 128 * 16;   // bytes per SNP block (all parts)
     aq_v2 p0, p1, q0, q1, c0, c1, d0, d1;   // XU tiles alternate between (p0,p1) and (q0,q1), XA tiles between (c0,c1) and (d0,d1)
+    // DEEP (one trait tile per workgroup: a tile step is only 8 MFMAs = 0.21 us, less than an L2 hit, and there are registers to
+    // spare): three buffers per stream, every request one step earlier -- XU(t+2) and XA(t+1) at the start of step t, tiles 0 and
+    // 1 of XU and tile 0 of XA of the NEXT phase at the end of the last step.  Tile k of a stream lives in buffer k % 3.  Issue
+    // order of a phase: [XU0 XA0 XU1] (dangling from the phase before), then per step t: XU(t+2), XA(t+1) while they exist, then
+    // XU'0, XA'0, XU'1.  So XU(k) is request number 0, 2 for k = 0, 1 and 2k - 1 beyond; XA(k) number 1 for k = 0, 2k + 2
+    // beyond; after the requests of step t, 2t + 5 are out (2 last + 2 in the last two steps) -- every wait below is
+    // vmcnt(2 x (requests issued after the wanted one)).
+    constexpr bool DEEP = (TT == 1) && (NTC >= 4);
+    aq_v2 xb[DEEP ? 3 : 1][2], ab[DEEP ? 3 : 1][2];
     // Tile step t: U(t) = 4 TT MFMAs chained on Rr[.][t]; S(t-1) = 4 TT chained on acc, whose B operand Rr[.][t-1] was
     // finished a whole step earlier.  Loads, all issued at the START of a step: XU(t+1) (used one step later) and XA(t)
     // (used by S(t), one and a half steps later); tile 0 of the NEXT phase at the end of the last step.  Queue of
@@ -302,8 +316,14 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     //   t>=2: [XU(t) XA(t-1) | XU(t+1) XA(t)]   wait XU(t) = vmcnt(6), then XA(t-1) = vmcnt(4)
     //   last: [XU(t) XA(t-1) | XA(t)]  vmcnt(4), vmcnt(2) (two tiles only: [XA0 XU1 | XA1] vmcnt(2)); then +XU'0: [XA(t) XU'0]
     //         vmcnt(2); then +XA'0.
-    AQ_LD2(p0, p1, voff, XUb + seg_b0 * BLK);
-    AQ_LD2(c0, c1, voff, XAb + seg_b0 * BLK);
+    if constexpr (DEEP) {
+      AQ_LD2I(xb[0][0], xb[0][1], voff, XUb + seg_b0 * BLK, 0);
+      AQ_LD2I(ab[0][0], ab[0][1], voff, XAb + seg_b0 * BLK, 0);
+      AQ_LD2I(xb[1][0], xb[1][1], voff, XUb + seg_b0 * BLK, 2048);
+    } else {
+      AQ_LD2(p0, p1, voff, XUb + seg_b0 * BLK);
+      AQ_LD2(c0, c1, voff, XAb + seg_b0 * BLK);
+    }
     for (int i = 0; i <= nblk + 1; i++) {
       const bool do_u = i >= 2, do_s = i < nblk_s;
       const double mflag = do_u ? -1.0 : 0.0;
@@ -356,7 +376,47 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           acc[tt] = aq_mfma(x1.y, Rp[3], acc[tt]);
         });
       };
-      if constexpr (NTC == 1) {
+      if constexpr (DEEP) {
+        aq_static_for<NTC>([&](auto tc) __attribute__((always_inline)) {
+          constexpr int t = decltype(tc)::value, last = NTC - 1;
+          using TP = std::integral_constant<int, (t > 0 ? t - 1 : 0)>;
+          if constexpr (t + 2 <= last) {
+            constexpr int k = t + 2, kb = (k + 2) / 4, imm = (k - 4 * kb) * 2048;
+            AQ_LD2I(xb[k % 3][0], xb[k % 3][1], voff, xu + kb * 8192, imm);
+          }
+          if constexpr (t + 1 <= last) {
+            constexpr int k = t + 1, kb = (k + 2) / 4, imm = (k - 4 * kb) * 2048;
+            AQ_LD2I(ab[k % 3][0], ab[k % 3][1], voff, xa + kb * 8192, imm);
+          }
+          constexpr int issued = t <= last - 2 ? 2 * t + 5 : 2 * last + 2;
+          constexpr int posU = t == 0 ? 0 : t == 1 ? 2 : 2 * t - 1;
+          aq_wait2n<2 * (issued - 1 - posU)>(xb[t % 3][0], xb[t % 3][1]);
+          U(tc, xb[t % 3][0], xb[t % 3][1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (t >= 1) {
+            constexpr int k = t - 1, posA = k == 0 ? 1 : 2 * k + 2;
+            aq_wait2n<2 * (issued - 1 - posA)>(ab[k % 3][0], ab[k % 3][1]);
+            S(TP{}, ab[k % 3][0], ab[k % 3][1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (MASK) {
+            remask(tc);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (t == last) {
+            AQ_LD2I(xb[0][0], xb[0][1], voff, nxu, 0);          // XU'0: every U of this phase is issued
+            aq_wait2n<2>(ab[last % 3][0], ab[last % 3][1]);     // XA(last): only XU'0 is younger
+            S(tc, ab[last % 3][0], ab[last % 3][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            AQ_LD2I(ab[0][0], ab[0][1], voff, nxa, 0);          // XA'0, XU'1
+            AQ_LD2I(xb[1][0], xb[1][1], voff, nxu, 2048);
+          }
+          if constexpr (HI && t + 1 == ST) {
+            if (a.stagger) signal(8 + mw, i + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else if constexpr (NTC == 1) {
         using C0 = std::integral_constant<int, 0>;
         AQ_WAIT2(0, p0, p1);
         AQ_WAIT2(0, c0, c1);
@@ -426,7 +486,11 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       signal(ROLE == 2 ? 11 : mw, i + 1);
       tl_mark(i, 3);                     // S' stored and announced
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(c0), "+v"(c1), "+v"(q0), "+v"(q1), "+v"(d0), "+v"(d1));   // the dangling prefetch
+    if constexpr (DEEP)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[1][0]), "+v"(xb[1][1]), "+v"(xb[2][0]), "+v"(xb[2][1]),
+                                          "+v"(ab[0][0]), "+v"(ab[0][1]), "+v"(ab[1][0]), "+v"(ab[1][1]), "+v"(ab[2][0]), "+v"(ab[2][1]));
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(c0), "+v"(c1), "+v"(q0), "+v"(q1), "+v"(d0), "+v"(d1));   // the dangling prefetch
     // ---- write the residual back and ||R_k||^2 partials ----
     // (lane id and base pointer are re-derived behind an optimisation barrier: otherwise the addresses computed for
     // the loads at the top are kept alive -- i.e. spilled -- across the whole sweep)
