@@ -298,14 +298,17 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     const char *XUb = (const char *)a.XU, *XAb = (const char *)a.XA;
     const long long BLK = (long long)NTT * C * 128 * 16;   // bytes per SNP block (all parts)
     aq_v2 p0, p1, q0, q1, c0, c1, d0, d1;   // XU tiles alternate between (p0,p1) and (q0,q1), XA tiles between (c0,c1) and (d0,d1)
-    // DEEP (one trait tile per workgroup: a tile step is only 8 MFMAs = 0.21 us, less than an L2 hit, and there are registers to
-    // spare): three buffers per stream, every request one step earlier -- XU(t+2) and XA(t+1) at the start of step t, tiles 0 and
+    // DEEP (above all one trait tile per workgroup: a tile step is only 8 MFMAs = 0.21 us, less than an L2 hit, and there are
+    // registers to spare): three buffers per stream, every request one step earlier -- XU(t+2) and XA(t+1) at the start of step t, tiles 0 and
     // 1 of XU and tile 0 of XA of the NEXT phase at the end of the last step.  Tile k of a stream lives in buffer k % 3.  Issue
     // order of a phase: [XU0 XA0 XU1] (dangling from the phase before), then per step t: XU(t+2), XA(t+1) while they exist, then
     // XU'0, XA'0, XU'1.  So XU(k) is request number 0, 2 for k = 0, 1 and 2k - 1 beyond; XA(k) number 1 for k = 0, 2k + 2
     // beyond; after the requests of step t, 2t + 5 are out (2 last + 2 in the last two steps) -- every wait below is
     // vmcnt(2 x (requests issued after the wanted one)).
-    constexpr bool DEEP = (TT == 1) && (NTC >= 4);
+    // With two trait tiles only the matrix waves of the geometries NT / NT - 1 take part (C3's post-annealing instance 10 / 9 / 6:
+    // 34.55 -> 34.3 ms): the recurrence wave has no register left, and in the NT / NT geometries (the annealed sweeps' 10 / 10 / 3)
+    // the sixteen registers make the matrix waves spill (measured: 1 % slower).
+    constexpr bool DEEP = (NTC >= 4) && (TT == 1 || (ROLE != 2 && NT2 != NT));
     aq_v2 xb[DEEP ? 3 : 1][2], ab[DEEP ? 3 : 1][2];
     // Tile step t: U(t) = 4 TT MFMAs chained on Rr[.][t]; S(t-1) = 4 TT chained on acc, whose B operand Rr[.][t-1] was
     // finished a whole step earlier.  Loads, all issued at the START of a step: XU(t+1) (used one step later) and XA(t)
