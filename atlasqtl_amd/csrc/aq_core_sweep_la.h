@@ -114,6 +114,41 @@ __device__ __forceinline__ void aq_wait2n(aq_v2 &d0, aq_v2 &d1) {   // the same 
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(d0), "+v"(d1) : "n"(N));
 }
 
+// Operand prefetch with D buffers per stream (tile k in buffer k % D).  Request order of a phase: the tiles left dangling by the
+// phase before -- [XU0 XA0 XU1 XA1 ...], XU up to tile D-2, XA up to D-3 -- then per step t: XU(t+D-1), XA(t+D-2) while they
+// exist.  aq_req_index = position of a request in that order, aq_req_issued = requests out after the issues of step t; a wait
+// for a tile is vmcnt(2 x (requests issued after it)): two loads per request, completed in order.
+constexpr int aq_req_index(int D, int last, int stream /* 0 XU, 1 XA */, int k) {
+  int n = 0;
+  for (int j = 0; j <= D - 2; j++) {
+    if (stream == 0 && k == j) return n;
+    n++;
+    if (j <= D - 3) {
+      if (stream == 1 && k == j) return n;
+      n++;
+    }
+  }
+  for (int t = 0; t <= last; t++) {
+    if (t + D - 1 <= last) {
+      if (stream == 0 && k == t + D - 1) return n;
+      n++;
+    }
+    if (t + D - 2 <= last) {
+      if (stream == 1 && k == t + D - 2) return n;
+      n++;
+    }
+  }
+  return -1;
+}
+constexpr int aq_req_issued(int D, int last, int t) {
+  int n = (D - 1) + (D - 2);
+  for (int s = 0; s <= t; s++) n += (s + D - 1 <= last) + (s + D - 2 <= last);
+  return n;
+}
+#ifndef AQ_DEEP_TT1
+#define AQ_DEEP_TT1 4   // buffers per operand stream of the one-tile workgroups
+#endif
+
 // NT = residual tiles of matrix waves 0,1,2; NT2 (= NT or NT-1) those of waves 4,5,6: each SIMD carries NT + NT2.
 // SEG: chained-segment launch (a.nseg * nwg workgroups).  Workgroup s*nwg + k handles SNP segment s of trait-tile group
 // k, starting from the residual that segment s-1 of the same group left in global memory.  Blocks are dispatched in
@@ -299,17 +334,17 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     const long long BLK = (long long)NTT * C * 128 * 16;   // bytes per SNP block (all parts)
     aq_v2 p0, p1, q0, q1, c0, c1, d0, d1;   // XU tiles alternate between (p0,p1) and (q0,q1), XA tiles between (c0,c1) and (d0,d1)
     // DEEP (above all one trait tile per workgroup: a tile step is only 8 MFMAs = 0.21 us, less than an L2 hit, and there are
-    // registers to spare): three buffers per stream, every request one step earlier -- XU(t+2) and XA(t+1) at the start of step t, tiles 0 and
-    // 1 of XU and tile 0 of XA of the NEXT phase at the end of the last step.  Tile k of a stream lives in buffer k % 3.  Issue
-    // order of a phase: [XU0 XA0 XU1] (dangling from the phase before), then per step t: XU(t+2), XA(t+1) while they exist, then
-    // XU'0, XA'0, XU'1.  So XU(k) is request number 0, 2 for k = 0, 1 and 2k - 1 beyond; XA(k) number 1 for k = 0, 2k + 2
-    // beyond; after the requests of step t, 2t + 5 are out (2 last + 2 in the last two steps) -- every wait below is
-    // vmcnt(2 x (requests issued after the wanted one)).
-    // With two trait tiles only the matrix waves of the geometries NT / NT - 1 take part (C3's post-annealing instance 10 / 9 / 6:
-    // 34.55 -> 34.3 ms): the recurrence wave has no register left, and in the NT / NT geometries (the annealed sweeps' 10 / 10 / 3)
-    // the sixteen registers make the matrix waves spill (measured: 1 % slower).
-    constexpr bool DEEP = (NTC >= 4) && (TT == 1 || (ROLE != 2 && NT2 != NT));
-    aq_v2 xb[DEEP ? 3 : 1][2], ab[DEEP ? 3 : 1][2];
+    // registers to spare): DB = 3 or 4 buffers per stream instead of two, every request one or two steps earlier -- XU(t+DB-1) and
+    // XA(t+DB-2) at the start of step t, the first tiles of the NEXT phase at the end of the last step (aq_req_index above).
+    // The destination registers of these requests are written long after the asm statement that names them, which the compiler
+    // cannot know: were it to spill one of them in between, the returning load would overwrite whatever lives in that register by
+    // then (this is what a GPU fault with four buffers in a 256-register MASK instance came down to).  The deeper schemes are
+    // therefore used only where the instance has registers to spare and no scratch at all: four buffers for complete Y up to 11
+    // tiles per wave (207 - 219 VGPRs), three for complete Y beyond (<= 229) and for the chained MASK instances (232: C3 with NA);
+    // the other MASK instances and all two-tile instances (256 VGPRs, some scratch) keep the two-buffer scheme below.
+    constexpr bool DEEP = (TT == 1) && (NTC >= 4) && (!MASK || (SEG && NT <= 11));
+    constexpr int DB = !DEEP ? 1 : (!MASK && NT <= 11) ? AQ_DEEP_TT1 : 3;
+    aq_v2 xb[DB][2], ab[DB][2];
     // Tile step t: U(t) = 4 TT MFMAs chained on Rr[.][t]; S(t-1) = 4 TT chained on acc, whose B operand Rr[.][t-1] was
     // finished a whole step earlier.  Loads, all issued at the START of a step: XU(t+1) (used one step later) and XA(t)
     // (used by S(t), one and a half steps later); tile 0 of the NEXT phase at the end of the last step.  Queue of
@@ -319,10 +354,22 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     //   t>=2: [XU(t) XA(t-1) | XU(t+1) XA(t)]   wait XU(t) = vmcnt(6), then XA(t-1) = vmcnt(4)
     //   last: [XU(t) XA(t-1) | XA(t)]  vmcnt(4), vmcnt(2) (two tiles only: [XA0 XU1 | XA1] vmcnt(2)); then +XU'0: [XA(t) XU'0]
     //         vmcnt(2); then +XA'0.
+    // the dangling requests [XU0 XA0 XU1 XA1 ...] of a phase whose operands start at xu0 / xa0 (tiles 0 .. 3 share one base)
+    auto dangling = [&](const char *xu0, const char *xa0, auto skip_first) __attribute__((always_inline)) {
+      aq_static_for<DB - 1>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (!(decltype(skip_first)::value && j == 0)) {
+          constexpr int kb = (j + 2) / 4, imm = (j - 4 * kb) * 2048;
+          AQ_LD2I(xb[j][0], xb[j][1], voff, xu0 + kb * 8192, imm);
+        }
+        if constexpr (j <= DB - 3) {
+          constexpr int kb = (j + 2) / 4, imm = (j - 4 * kb) * 2048;
+          AQ_LD2I(ab[j][0], ab[j][1], voff, xa0 + kb * 8192, imm);
+        }
+      });
+    };
     if constexpr (DEEP) {
-      AQ_LD2I(xb[0][0], xb[0][1], voff, XUb + seg_b0 * BLK, 0);
-      AQ_LD2I(ab[0][0], ab[0][1], voff, XAb + seg_b0 * BLK, 0);
-      AQ_LD2I(xb[1][0], xb[1][1], voff, XUb + seg_b0 * BLK, 2048);
+      dangling(XUb + seg_b0 * BLK, XAb + seg_b0 * BLK, std::false_type{});
     } else {
       AQ_LD2(p0, p1, voff, XUb + seg_b0 * BLK);
       AQ_LD2(c0, c1, voff, XAb + seg_b0 * BLK);
@@ -383,23 +430,22 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         aq_static_for<NTC>([&](auto tc) __attribute__((always_inline)) {
           constexpr int t = decltype(tc)::value, last = NTC - 1;
           using TP = std::integral_constant<int, (t > 0 ? t - 1 : 0)>;
-          if constexpr (t + 2 <= last) {
-            constexpr int k = t + 2, kb = (k + 2) / 4, imm = (k - 4 * kb) * 2048;
-            AQ_LD2I(xb[k % 3][0], xb[k % 3][1], voff, xu + kb * 8192, imm);
+          if constexpr (t + DB - 1 <= last) {
+            constexpr int k = t + DB - 1, kb = (k + 2) / 4, imm = (k - 4 * kb) * 2048;
+            AQ_LD2I(xb[k % DB][0], xb[k % DB][1], voff, xu + kb * 8192, imm);
           }
-          if constexpr (t + 1 <= last) {
-            constexpr int k = t + 1, kb = (k + 2) / 4, imm = (k - 4 * kb) * 2048;
-            AQ_LD2I(ab[k % 3][0], ab[k % 3][1], voff, xa + kb * 8192, imm);
+          if constexpr (t + DB - 2 <= last) {
+            constexpr int k = t + DB - 2, kb = (k + 2) / 4, imm = (k - 4 * kb) * 2048;
+            AQ_LD2I(ab[k % DB][0], ab[k % DB][1], voff, xa + kb * 8192, imm);
           }
-          constexpr int issued = t <= last - 2 ? 2 * t + 5 : 2 * last + 2;
-          constexpr int posU = t == 0 ? 0 : t == 1 ? 2 : 2 * t - 1;
-          aq_wait2n<2 * (issued - 1 - posU)>(xb[t % 3][0], xb[t % 3][1]);
-          U(tc, xb[t % 3][0], xb[t % 3][1]);
+          constexpr int issued = aq_req_issued(DB, last, t);
+          aq_wait2n<2 * (issued - 1 - aq_req_index(DB, last, 0, t))>(xb[t % DB][0], xb[t % DB][1]);
+          U(tc, xb[t % DB][0], xb[t % DB][1]);
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (t >= 1) {
-            constexpr int k = t - 1, posA = k == 0 ? 1 : 2 * k + 2;
-            aq_wait2n<2 * (issued - 1 - posA)>(ab[k % 3][0], ab[k % 3][1]);
-            S(TP{}, ab[k % 3][0], ab[k % 3][1]);
+            constexpr int k = t - 1;
+            aq_wait2n<2 * (issued - 1 - aq_req_index(DB, last, 1, k))>(ab[k % DB][0], ab[k % DB][1]);
+            S(TP{}, ab[k % DB][0], ab[k % DB][1]);
             __builtin_amdgcn_sched_barrier(0);
           }
           if constexpr (MASK) {
@@ -408,11 +454,10 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           }
           if constexpr (t == last) {
             AQ_LD2I(xb[0][0], xb[0][1], voff, nxu, 0);          // XU'0: every U of this phase is issued
-            aq_wait2n<2>(ab[last % 3][0], ab[last % 3][1]);     // XA(last): only XU'0 is younger
-            S(tc, ab[last % 3][0], ab[last % 3][1]);
+            aq_wait2n<2 * (issued - 1 - aq_req_index(DB, last, 1, last) + 1)>(ab[last % DB][0], ab[last % DB][1]);   // XA(last)
+            S(tc, ab[last % DB][0], ab[last % DB][1]);
             __builtin_amdgcn_sched_barrier(0);
-            AQ_LD2I(ab[0][0], ab[0][1], voff, nxa, 0);          // XA'0, XU'1
-            AQ_LD2I(xb[1][0], xb[1][1], voff, nxu, 2048);
+            dangling(nxu, nxa, std::true_type{});               // XA'0, XU'1, ... (XU'0 is out already)
           }
           if constexpr (HI && t + 1 == ST) {
             if (a.stagger) signal(8 + mw, i + 1);
@@ -489,9 +534,13 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       signal(ROLE == 2 ? 11 : mw, i + 1);
       tl_mark(i, 3);                     // S' stored and announced
     }
-    if constexpr (DEEP)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[1][0]), "+v"(xb[1][1]), "+v"(xb[2][0]), "+v"(xb[2][1]),
-                                          "+v"(ab[0][0]), "+v"(ab[0][1]), "+v"(ab[1][0]), "+v"(ab[1][1]), "+v"(ab[2][0]), "+v"(ab[2][1]));
+    if constexpr (DEEP) {   // the dangling prefetch (the empty statements tie the wait to every buffer)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(ab[0][0]), "+v"(ab[0][1]));
+      if constexpr (DB > 1) asm volatile("" : "+v"(xb[DB > 1 ? 1 : 0][0]), "+v"(xb[DB > 1 ? 1 : 0][1]), "+v"(ab[DB > 1 ? 1 : 0][0]), "+v"(ab[DB > 1 ? 1 : 0][1]));
+      if constexpr (DB > 2) asm volatile("" : "+v"(xb[DB > 2 ? 2 : 0][0]), "+v"(xb[DB > 2 ? 2 : 0][1]), "+v"(ab[DB > 2 ? 2 : 0][0]), "+v"(ab[DB > 2 ? 2 : 0][1]));
+      if constexpr (DB > 3) asm volatile("" : "+v"(xb[DB > 3 ? 3 : 0][0]), "+v"(xb[DB > 3 ? 3 : 0][1]), "+v"(ab[DB > 3 ? 3 : 0][0]), "+v"(ab[DB > 3 ? 3 : 0][1]));
+    }
     else
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(c0), "+v"(c1), "+v"(q0), "+v"(q1), "+v"(d0), "+v"(d1));   // the dangling prefetch
     // ---- write the residual back and ||R_k||^2 partials ----
