@@ -37,14 +37,13 @@ PEAK_FP64_MFMA_MEASURED_TFLOPS = 77.8
 # HBM-side bytes of ONE core-sweep launch at the default workload on one GPU, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command with the gfx950
 # correction (FETCH_SIZE x 2 for coalesced streaming reads, calibrated on aq_k_prepass's gam read):
-# profiles/r02_pmc_hbm_traffic_v5.txt (the post-annealing instance <10, 9, true, 2>: reads 2 x 11,713,127 KiB + writes 9,925,281 KiB;
+# profiles/r02_pmc_hbm_traffic_v6.txt (the post-annealing instance <10, 9, true, 2>: reads 2 x 12,875,608 KiB + writes 8,430,415 KiB;
 # the reads include the helper waves' L2 warm-up touches).  PMC counters cannot be read from inside the timed run, so this is the
 # profile's number for the same kernel and workload, not a value measured in this run.
-PMC_TRAFFIC_C3_BYTES = 3.42e10
+PMC_TRAFFIC_C3_BYTES = 3.50e10
 # the same workload with 5 % of Y missing (AQ_BENCH_NA=0.05: the MASK instance of the look-ahead kernel, which streams the
-# traits' own Gram blocks, 98 GB per sweep): profiles/r02_pmc_hbm_traffic_c3_na5_v4.txt (2 x 100,416,653 KiB + 8,769,824 KiB; the
-# twelve profiled launches spread from 63e6 to 117e6 KiB of FETCH_SIZE)
-PMC_TRAFFIC_C3_NA5_BYTES = 2.15e11
+# traits' own Gram blocks, 98 GB per sweep): profiles/r02_pmc_hbm_traffic_c3_na5_v5.txt (2 x 72,413,656 KiB + 8,769,794 KiB)
+PMC_TRAFFIC_C3_NA5_BYTES = 1.57e11
 
 
 def build_problem(n, p, q_total, k0, k1, device, seed=123):
