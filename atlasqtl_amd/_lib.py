@@ -111,6 +111,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise AtlasqtlHipError(f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; "
                                    "g.build()' or make -C atlasqtl_amd/csrc). There is no CPU fallback.")
+        # PyTorch (used for device tensors and torch.distributed) ships its own copy of the HIP runtime.  If it is loaded AFTER this
+        # library has initialised the system copy, torch.cuda no longer finds a device ("No HIP GPUs are available"); loaded first,
+        # both live together.  So: torch first, when it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -537,7 +537,9 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       // two trait tiles per workgroup once that still gives every CU a workgroup (C3: 625 tiles -> 313 workgroups of 32
       // traits): X operands shared by two MFMAs, one chain evaluation per 32 traits, half the per-phase overhead.
       // q is then padded to a multiple of 32 (the extra tile is all padding: zero residual, masked sums).
-      s->TT = ((s->ntile + 1) / 2 >= s->ncu) ? 2 : 1;
+      // (Crossover measured at n = 1000, 256 CUs: 448 tiles -- one round of two-tile workgroups, 27.4 ms, against 1.75 rounds of
+      // one-tile workgroups; q = 8000: 27.5 vs 31.1 ms, q = 6144: 27.5 vs 23.4.)
+      s->TT = (4LL * s->ntile >= 7LL * s->ncu) ? 2 : 1;
       if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 2 ? 2 : 1;
       if (s->la_mask) s->TT = 1;   // 16 per-trait Gram blocks per trait tile in LDS: one tile per workgroup
       if (s->TT == 2) {
