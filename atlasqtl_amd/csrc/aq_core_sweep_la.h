@@ -337,11 +337,13 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     // registers to spare): DB = 3 or 4 buffers per stream instead of two, every request one or two steps earlier -- XU(t+DB-1) and
     // XA(t+DB-2) at the start of step t, the first tiles of the NEXT phase at the end of the last step (aq_req_index above).
     // The destination registers of these requests are written long after the asm statement that names them, which the compiler
-    // cannot know: were it to spill one of them in between, the returning load would overwrite whatever lives in that register by
-    // then (this is what a GPU fault with four buffers in a 256-register MASK instance came down to).  The deeper schemes are
-    // therefore used only where the instance has registers to spare and no scratch at all: four buffers for complete Y up to 11
-    // tiles per wave (207 - 219 VGPRs), three for complete Y beyond (<= 229) and for the chained MASK instances (232: C3 with NA);
-    // the other MASK instances and all two-tile instances (256 VGPRs, some scratch) keep the two-buffer scheme below.
+    // cannot know: a spill of one of them between request and use would be overwritten by the returning load.  Four buffers in a
+    // 256-register MASK instance (NT = 14, 76 B of scratch) ended in a GPU fault whose cause was not established --
+    // tools/check_isa_spills.py finds no such spill in that build, and the request / wait protocol checks out for every tile
+    // count (tests/test_host_logic.py) -- so, as a precaution, the deeper schemes are compiled only into instances without any
+    // scratch: four buffers for complete Y up to 11 tiles per wave (207 - 219 VGPRs), three for complete Y beyond (<= 229) and for
+    // the chained MASK instances (232: C3 with NA); the other MASK instances and all two-tile instances (256 VGPRs, some
+    // scratch) keep the two-buffer scheme below.
     constexpr bool DEEP = (TT == 1) && (NTC >= 4) && (!MASK || (SEG && NT <= 11));
     constexpr int DB = !DEEP ? 1 : (!MASK && NT <= 11) ? AQ_DEEP_TT1 : 3;
     aq_v2 xb[DB][2], ab[DB][2];

@@ -111,3 +111,83 @@ def test_list_dimension_checks():
         H.prepare_list_hyper_(bad, Yc, p, (2, 4), bool_rmvd_x)
     with pytest.raises(A.AtlasqtlError, match="must be an object of class"):
         H.prepare_list_hyper_({"q_hyper": 4}, Yc, p, (2, 4), bool_rmvd_x)
+
+
+def test_operand_prefetch_protocol_is_consistent():
+    """The request / wait protocol of the look-ahead kernel's deeper operand prefetch (atlasqtl_amd/csrc/aq_core_sweep_la.h:
+    aq_req_index / aq_req_issued, D buffers per stream, tile k in buffer k % D, every wait = vmcnt(2 x requests issued after the
+    wanted one), loads complete in order), simulated on the host for every tile count and both depths over several phases:
+    every tile an MFMA consumes has returned by then and still sits in its buffer."""
+    def req_index(D, last, stream, k):
+        n = 0
+        for j in range(0, D - 1):
+            if stream == 0 and k == j:
+                return n
+            n += 1
+            if j <= D - 3:
+                if stream == 1 and k == j:
+                    return n
+                n += 1
+        for t in range(0, last + 1):
+            if t + D - 1 <= last:
+                if stream == 0 and k == t + D - 1:
+                    return n
+                n += 1
+            if t + D - 2 <= last:
+                if stream == 1 and k == t + D - 2:
+                    return n
+                n += 1
+        return -1
+
+    def req_issued(D, last, t):
+        return (D - 1) + (D - 2) + sum((s + D - 1 <= last) + (s + D - 2 <= last) for s in range(t + 1))
+
+    def simulate(NTC, D, phases=4):
+        last, queue, buf = NTC - 1, [], {}
+
+        def issue(stream, ph, k):
+            queue.append((stream, ph, k))
+            buf[(stream, k % D)] = [ph, k, False]
+
+        def wait(vmcnt):
+            keep = vmcnt // 2
+            assert 0 <= vmcnt < 64
+            if keep < len(queue):
+                for (st, ph, k) in queue[:len(queue) - keep]:
+                    b = buf[(st, k % D)]
+                    if b[0] == ph and b[1] == k:
+                        b[2] = True
+                del queue[:len(queue) - keep]
+
+        def use(stream, ph, k):
+            assert buf[(stream, k % D)] == [ph, k, True], (NTC, D, stream, ph, k, buf[(stream, k % D)])
+
+        def dangling(ph, skip_first):
+            for j in range(0, D - 1):
+                if not (skip_first and j == 0):
+                    issue(0, ph, j)
+                if j <= D - 3:
+                    issue(1, ph, j)
+
+        dangling(0, False)
+        for ph in range(phases):
+            for t in range(NTC):
+                if t + D - 1 <= last:
+                    issue(0, ph, t + D - 1)
+                if t + D - 2 <= last:
+                    issue(1, ph, t + D - 2)
+                issued = req_issued(D, last, t)
+                wait(2 * (issued - 1 - req_index(D, last, 0, t)))
+                use(0, ph, t)
+                if t >= 1:
+                    wait(2 * (issued - 1 - req_index(D, last, 1, t - 1)))
+                    use(1, ph, t - 1)
+                if t == last:
+                    issue(0, ph + 1, 0)
+                    wait(2 * (issued - 1 - req_index(D, last, 1, last) + 1))
+                    use(1, ph, last)
+                    dangling(ph + 1, True)
+
+    for D in (3, 4):
+        for NTC in range(4, 19):
+            simulate(NTC, D)
