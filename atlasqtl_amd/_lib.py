@@ -74,6 +74,7 @@ SYMBOLS = {
     "aq_vb_get_status": (C.c_int, [C.c_void_p, C.POINTER(AqVbStatus)]),
     "aq_vb_get_elbo_trace": (C.c_int32, [C.c_void_p, ip, dp, C.c_int32]),
     "aq_vb_get_result": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
+    "aq_vb_get_residual": (C.c_int, [C.c_void_p, dp]),
     "aq_prepare_data": (C.c_int, [C.POINTER(AqPrepInput), C.POINTER(C.c_void_p)]),
     "aq_prep_info": (C.c_int, [C.c_void_p, ip, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), ip, dp, dp]),
     "aq_prep_x_device": (C.c_void_p, [C.c_void_p]),

@@ -381,6 +381,12 @@ class VbRun:
         n = lib().aq_vb_get_elbo_trace(self.h, as_ip(its), as_dp(lbs), cap)
         return its[:n].copy(), lbs[:n].copy()
 
+    def residual(self):
+        """mis_pat .* (Y - X beta_vb) as the sweep kernel carries it (n x q), see aq_vb_get_residual."""
+        R = np.zeros((self.n, self.q), order="F")
+        check(lib().aq_vb_get_residual(self.h, as_dp(R)), "aq_vb_get_residual")
+        return R
+
     def result(self, full_output=False):
         p, q = self.p, self.q
         beta = np.zeros((p, q), order="F"); gam = np.zeros((p, q), order="F")

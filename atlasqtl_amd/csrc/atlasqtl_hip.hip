@@ -1365,6 +1365,26 @@ extern "C" int aq_vb_get_result(aq_vb_handle s, double *beta_vb, double *gam_vb,
   return AQ_OK;
 }
 
+// The residual the sweep kernel carries in n-space, mis_pat .* (Y - X beta_vb) (= what cp_Y_X - cp_betaX_X of the reference
+// encodes, src/coreLoop.cpp:71,81), n x q column-major.  It is only ever updated incrementally (R -= X delta per SNP block and
+// sweep), so comparing it with Y - X beta_vb recomputed from the returned beta_vb measures the rounding drift of a whole run.
+extern "C" int aq_vb_get_residual(aq_vb_handle s, double *R_out) {
+  if (!s || !R_out) return aq_fail(AQ_ERR_ARG, "NULL argument");
+  AQ_HIP(hipSetDevice(s->device));
+  AQ_HIP(hipDeviceSynchronize());
+  AQ_TRY(aq_check_chain_error(s));
+  if (s->use_tw && s->WPT > 1) return aq_fail(AQ_ERR_UNSUPPORTED, "aq_vb_get_residual: not for the generic kernel's split layout");
+  const size_t nq = (size_t)s->n * s->q;
+  double *stage = nullptr;
+  AQ_HIP(hipMalloc((void **)&stage, nq * sizeof(double)));
+  hipLaunchKernelGGL(aq_k_colmajor_from_tile, dim3((s->n_pad + 63) / 64, s->ntile), dim3(256), 0, 0, s->R, (const double *)nullptr,
+                     stage, s->n, s->q, s->n_pad);
+  hipError_t e = hipMemcpy(R_out, stage, nq * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(stage);
+  if (e != hipSuccess) return aq_fail(AQ_ERR_DEVICE, hipGetErrorString(e));
+  return AQ_OK;
+}
+
 // ------------------------------------------------- operator-level entries ----
 static int aq_gram_common(bool mis, const double *cp_X, const double *const *cp_X_rm, const double *cp_Y_X, double *gam_vb,
                           const double *lP, const double *l1, double log_sig2_inv_vb, const double *log_tau_vb,

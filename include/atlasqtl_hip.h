@@ -187,6 +187,12 @@ int aq_vb_get_result(aq_vb_handle h, double *beta_vb, double *gam_vb, double *mu
                      double *zeta_vb, double *lam2_inv_vb, double *sig2_theta_vb, double *tau_vb,
                      double *sig2_beta_vb);
 
+/* The residual the sweep carries in n-space, mis_pat .* (Y - X beta_vb), n x q column-major, copied to the host: what
+ * cp_Y_X - cp_betaX_X encodes in the reference (src/coreLoop.cpp:71,81; R/atlasqtl_global_local_core.R:42,115).  It is
+ * updated incrementally for the whole run, so its distance from Y - X beta_vb recomputed from aq_vb_get_result is the
+ * accumulated rounding drift (tests/test_gpu_bigp.py). */
+int aq_vb_get_residual(aq_vb_handle h, double *R_out);
+
 /* ------------------------------------------------------------------------------------------
  * Input construction on the device: the O(n p) part of
  *     prepare_data_(Y, X, ...)                                      R/prepare_atlasqtl.R:8-87

@@ -83,9 +83,24 @@ def _F(a):
 # native inner loop (C restatement of src/coreLoop.cpp) -- in-place, R layout
 # ----------------------------------------------------------------------------
 def core_dual_loop(cp_X, cp_Y_X, gam_vb, log_Phi, log_1mPhi, log_sig2_inv_vb, log_tau_vb, m1_beta,
-                   cp_betaX_X, mu_beta_vb, sig2_beta_vb, tau_vb, shuffled_ind, sample_q, c=1.0):
+                   cp_betaX_X, mu_beta_vb, sig2_beta_vb, tau_vb, shuffled_ind, sample_q, c=1.0, threads=1):
     """src/coreLoop.cpp:38-86 through the C restatement.  All 2-D arrays must be
-    Fortran-ordered float64; gam_vb, m1_beta, cp_betaX_X, mu_beta_vb are mutated."""
+    Fortran-ordered float64; gam_vb, m1_beta, cp_betaX_X, mu_beta_vb are mutated.
+    threads > 1: the trait list sample_q is cut into that many pieces, one C call each on its own host
+    thread -- a trait's pass reads and writes only its own columns (:58-59), so the results are those
+    of the single call whatever the thread count (used for the BASELINE-size parity tests)."""
+    if threads > 1 and len(sample_q) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        sq_all = np.ascontiguousarray(sample_q, dtype=np.int32)
+        t = min(int(threads), len(sq_all))
+        cuts = [len(sq_all) * i // t for i in range(t + 1)]
+        with ThreadPoolExecutor(t) as ex:
+            futs = [ex.submit(core_dual_loop, cp_X, cp_Y_X, gam_vb, log_Phi, log_1mPhi, log_sig2_inv_vb, log_tau_vb,
+                              m1_beta, cp_betaX_X, mu_beta_vb, sig2_beta_vb, tau_vb, shuffled_ind,
+                              sq_all[cuts[i]:cuts[i + 1]], c, 1) for i in range(t)]
+            for f in futs:
+                f.result()
+        return
     p, q = gam_vb.shape
     for a in (cp_X, cp_Y_X, gam_vb, log_Phi, log_1mPhi, m1_beta, cp_betaX_X, mu_beta_vb):
         assert a.flags.f_contiguous and a.dtype == np.float64
@@ -531,7 +546,7 @@ def atlasqtl_global_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_hyper,
 
 def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_hyper, list_init,
                                 thinned_elbo_eval=True, debug=True, inner="c", trace=None,
-                                full_output=False, scheme="global_local"):
+                                full_output=False, scheme="global_local", threads=1):
     """Restatement of atlasqtl_global_local_core_ (batch == "y").  scheme = "global": the p-vector part and the ELBO of
     atlasqtl_global_core_ (R/atlasqtl_global_core.R:236-256,372-421) instead; df in {1, 3} (df = 3 without annealing:
     the annealed update of lam2_inv_vb needs Kummer's 1F1, R/update_vb.R:76-81).  Y may contain
@@ -637,7 +652,7 @@ def atlasqtl_global_local_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, list_
         if inner == "c":                                                              # :166-176
             if mis_pat is None:
                 core_dual_loop(cp_X, cp_Y_X, gam_vb, log_Phi, log_1mPhi, log_sig2_inv_vb, log_tau_vb, beta_vb,
-                               cp_X_Xbeta, mu_beta_vb, sig2_beta_vb, tau_vb, shuffled_ind, sample_q, c=c)
+                               cp_X_Xbeta, mu_beta_vb, sig2_beta_vb, tau_vb, shuffled_ind, sample_q, c=c, threads=threads)
             else:
                 sig2_beta_vb = _F(sig2_beta_vb)
                 core_dual_mis_loop(cp_X, cp_X_rm, cp_Y_X, gam_vb, log_Phi, log_1mPhi, log_sig2_inv_vb,

@@ -23,14 +23,44 @@ from scipy import special as sp
 from . import atlasqtl_oracle as O
 
 
+def _nspace_threaded(threads, X, R, mis, xnorm, gam, lP, l1, log_sig2_inv, log_tau, m1, mu, sig2_beta, tau, c):
+    """The C n-space loop (oracle_nspace_loop) over contiguous trait ranges on `threads` host threads: traits are
+    independent inside the loop (src/coreLoop.cpp:58-59), every thread touches its own columns only, so the result does
+    not depend on the thread count (ctypes releases the GIL during the call)."""
+    q = gam.shape[1]
+    threads = max(1, min(int(threads), q))
+    if threads == 1:
+        O.nspace_loop(X, R, mis, xnorm, gam, lP, l1, log_sig2_inv, log_tau, m1, mu, sig2_beta, tau, c=c)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    cuts = [q * t // threads for t in range(threads + 1)]
+    with ThreadPoolExecutor(threads) as ex:
+        futs = [ex.submit(O.nspace_loop, X, R, mis, xnorm, gam, lP, l1, log_sig2_inv, log_tau, m1, mu, sig2_beta, tau,
+                          c, cuts[t], cuts[t + 1]) for t in range(threads) if cuts[t + 1] > cuts[t]]
+        for f in futs:
+            f.result()
+
+
 def run_sharded(Y, X, q_total, anneal, tol, maxit, list_hyper, list_init, allreduce=lambda v: v,
-                thinned_elbo_eval=True, debug=True, trace=None):
+                thinned_elbo_eval=True, debug=True, trace=None, threads=1, return_residual=False):
     """Y, the q-vectors of list_hyper / list_init and the p x q matrices hold THIS rank's traits;
-    X and the p-vectors are replicated.  Returns the same fields as the driver for the local traits."""
-    Y = np.asfortranarray(Y, dtype=np.float64)
+    X and the p-vectors are replicated.  Returns the same fields as the driver for the local traits.
+    Y may hold NaN (missing, R/atlasqtl_global_local_core.R:19-32): the n-space form of coreDualMisLoop
+    (src/coreLoop.cpp:91-138) is a masked residual with X_norm_sq = (X^2)' mis_pat in place of n - 1
+    (oracle_nspace_loop with a mask), so no p x p matrix per trait is needed and the check scales to
+    BASELINE-size p.  `threads`: host threads over the traits of the C loop (same results for any count)."""
+    Y = np.array(Y, dtype=np.float64, order="F")
     X = np.asfortranarray(X, dtype=np.float64)
     n, p = X.shape
     q = Y.shape[1]
+    if np.isnan(Y).any():                                       # :19-23
+        mis = np.asfortranarray(np.where(np.isnan(Y), 0.0, 1.0))
+        Y[np.isnan(Y)] = 0.0
+        XN = np.asfortranarray((X ** 2).T @ mis)                # X_norm_sq, p x q
+        nobs = mis.sum(axis=0)
+    else:
+        mis = XN = None
+        nobs = np.full(q, float(n))
     shr = float(q_total)
     eta, kappa, n0 = (np.asarray(list_hyper[k], dtype=np.float64) for k in ("eta", "kappa", "n0"))
     A2_inv, m0, nu, rho, t02 = (float(list_hyper[k]) for k in ("A2_inv", "m0", "nu", "rho", "t02"))
@@ -59,9 +89,20 @@ def run_sharded(Y, X, q_total, anneal, tol, maxit, list_hyper, list_init, allred
     vsld = -q_total * (np.log(t02) + np.log(p + t02_inv))
     xnorm = (X ** 2).sum(axis=0)
 
+    def col_sums(s2b):
+        """sum gam, sum m2, the X_norm_sq-weighted sum of m2 - beta^2 (R/update_vb.R:136-157 regrouped: complete Y has
+        X_norm_sq = n - 1 for every entry), sum gam (log sig2_beta + 1) of R/elbo.R:27-33"""
+        be = gam * mu
+        s2m = s2b[None, :] if s2b.ndim == 1 else s2b
+        m2 = (mu ** 2 + s2m) * gam
+        w = (n - 1.0) if XN is None else XN
+        return gam.sum(0), m2.sum(0), (w * (m2 - be ** 2)).sum(0), (gam * (np.log(s2m) + 1)).sum(0)
+
     beta = gam * mu
     R = np.asfortranarray(Y - X @ beta)
-    sg, sm2, sb2 = gam.sum(0), ((mu ** 2 + sig2_beta[None, :]) * gam).sum(0), (beta ** 2).sum(0)
+    if mis is not None:
+        R *= mis
+    sg, sm2, sxm, _ = col_sums(sig2_beta)
     rn = (R ** 2).sum(0)
     red = allreduce(np.concatenate([np.zeros(p), [sg.sum(), np.dot(tau, sm2), zeta.sum()]]))
     S_gam, T2 = red[p], red[p + 1]
@@ -76,10 +117,13 @@ def run_sharded(Y, X, q_total, anneal, tol, maxit, list_hyper, list_init, allred
         rho_vb = c * (rho + T2 / 2)
         sig2_inv = nu_vb / rho_vb
         log_sig2_inv = sp.digamma(nu_vb) - np.log(rho_vb)
-        eta_vb = c * (eta + n / 2 + sg / 2) - c + 1
-        kappa_vb = c * (kappa + (rn + (nm1 + sig2_inv) * sm2 - nm1 * sb2) / 2)
+        eta_vb = c * (eta + nobs / 2 + sg / 2) - c + 1
+        kappa_vb = c * (kappa + (rn + sig2_inv * sm2 + sxm) / 2)
         tau = eta_vb / kappa_vb
-        sig2_beta = 1 / (c * (nm1 + sig2_inv) * tau)
+        if XN is None:
+            sig2_beta = 1 / (c * (nm1 + sig2_inv) * tau)
+        else:
+            sig2_beta = np.asfortranarray(1 / (c * (XN + sig2_inv) * tau[None, :]))     # R/update_vb.R:45
         log_tau = sp.digamma(eta_vb) - np.log(kappa_vb)
         # ---- pre-pass (aq_k_prepass)
         u = theta[:, None] + zeta[None, :]
@@ -93,10 +137,9 @@ def run_sharded(Y, X, q_total, anneal, tol, maxit, list_hyper, list_init, allred
         a_z, b_z = u + imr0 / sc, (imr1 - imr0) / sc
         # ---- core sweep in n-space (aq_core_sweep_kernel): the oracle's C port
         m1 = np.asfortranarray(gam * mu)
-        O.nspace_loop(X, R, None, xnorm, gam, np.asfortranarray(lP), np.asfortranarray(l1), log_sig2_inv, log_tau,
-                      m1, mu, sig2_beta, tau, c=c)
-        beta = gam * mu
-        sg, sm2, sb2 = gam.sum(0), ((mu ** 2 + sig2_beta[None, :]) * gam).sum(0), (beta ** 2).sum(0)
+        _nspace_threaded(threads, X, R, mis, xnorm if XN is None else XN, gam, np.asfortranarray(lP),
+                         np.asfortranarray(l1), log_sig2_inv, log_tau, m1, mu, sig2_beta, tau, c)
+        sg, sm2, sxm, sgl = col_sums(sig2_beta)
         rn = (R ** 2).sum(0)
         rsZ_loc = a_z.sum(1) + (gam * b_z).sum(1)
         csZ = a_z.sum(0) + (gam * b_z).sum(0)
@@ -135,11 +178,11 @@ def run_sharded(Y, X, q_total, anneal, tol, maxit, list_hyper, list_init, allred
             un = theta[:, None] + zeta[None, :]
             lPn, l1n = sp.log_ndtr(un), sp.log_ndtr(-un)
             H = np.sum(gam * lPn + (1 - gam) * l1n - gam * np.log(gam + eps75) - (1 - gam) * np.log(1 - gam + eps75))
-            eta_e = eta + n / 2 + sg / 2
-            kappa_e = kappa + (rn + (nm1 + sig2_inv) * sm2 - nm1 * sb2) / 2
+            eta_e = eta + nobs / 2 + sg / 2
+            kappa_e = kappa + (rn + sig2_inv * sm2 + sxm) / 2
             log_tau_e = sp.digamma(eta_e) - np.log(kappa_e)
-            loc = np.array([H, np.dot(log_tau_e, sg), np.dot(sg, np.log(sig2_beta) + 1),
-                            np.sum(n * (log_tau_e - np.log(2 * np.pi)) / 2 - tau * (kappa_e - sm2 * sig2_inv / 2 - kappa)),
+            loc = np.array([H, np.dot(log_tau_e, sg), sgl.sum(),
+                            np.sum(nobs * (log_tau_e - np.log(2 * np.pi)) / 2 - tau * (kappa_e - sm2 * sig2_inv / 2 - kappa)),
                             np.sum((eta - eta_e) * log_tau_e - (kappa - kappa_e) * tau + eta * np.log(kappa)
                                    - eta_e * np.log(kappa_e) - sp.gammaln(eta) + sp.gammaln(eta_e)),
                             np.sum((zeta - n0) ** 2), 0.0, 0.0])
@@ -170,5 +213,8 @@ def run_sharded(Y, X, q_total, anneal, tol, maxit, list_hyper, list_init, allred
                 batch_conv = batch_sched[sum_exceed - 1]
         if trace is not None:
             trace.append(rec)
-    return dict(beta_vb=gam * mu, gam_vb=gam, mu_beta_vb=mu, theta_vb=theta, zeta_vb=zeta, tau_vb=tau,
-                converged=converged, it=it, lb_opt=lb_new, diff_lb=abs(lb_new - lb_old), lam2_inv_vb=lam)
+    out = dict(beta_vb=gam * mu, gam_vb=gam, mu_beta_vb=mu, theta_vb=theta, zeta_vb=zeta, tau_vb=tau,
+               converged=converged, it=it, lb_opt=lb_new, diff_lb=abs(lb_new - lb_old), lam2_inv_vb=lam)
+    if return_residual:
+        out["residual"] = R          # mis_pat .* (Y - X beta_vb), carried incrementally through every sweep
+    return out
