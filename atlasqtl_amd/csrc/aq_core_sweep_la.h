@@ -337,15 +337,28 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     // registers to spare): DB = 3 or 4 buffers per stream instead of two, every request one or two steps earlier -- XU(t+DB-1) and
     // XA(t+DB-2) at the start of step t, the first tiles of the NEXT phase at the end of the last step (aq_req_index above).
     // The destination registers of these requests are written long after the asm statement that names them, which the compiler
-    // cannot know: a spill of one of them between request and use would be overwritten by the returning load.  Four buffers in a
-    // 256-register MASK instance (NT = 14, 76 B of scratch) ended in a GPU fault whose cause was not established --
-    // tools/check_isa_spills.py finds no such spill in that build, and the request / wait protocol checks out for every tile
-    // count (tests/test_host_logic.py) -- so, as a precaution, the deeper schemes are compiled only into instances without any
-    // scratch: four buffers for complete Y up to 11 tiles per wave (207 - 219 VGPRs), three for complete Y beyond (<= 229) and for
-    // the chained MASK instances (232: C3 with NA); the other MASK instances and all two-tile instances (256 VGPRs, some
-    // scratch) keep the two-buffer scheme below.
+    // cannot know.  Under register pressure it splits their live ranges between request and wait: it copies the (stale) bits
+    // elsewhere, spills them, and hands the physical registers to other values -- which the returning load then overwrites
+    // (an LDS read of delta, an address: the GPU fault seen in round 2 with four buffers in a 256-register MASK instance).
+    // profiles/r03_isa_forced_deep.txt shows exactly that in <11, 11, SEG, 2> with four buffers forced (v_mov_b64 copies,
+    // a scratch_store and ds_read2_b64 into destinations in flight).  Nothing in the source can forbid it, so it is PROVEN
+    // ABSENT per build instead: `make` links the library only after tools/check_isa_operands.py has walked the control flow of
+    // every instance's shipped ISA, replayed vmcnt over the real instruction stream and found no instruction touching a
+    // destination while its request is in flight (profiles/r03_isa_proof.txt).  The depth per instance is then a matter of
+    // measurement only: four buffers for complete Y up to 11 tiles per wave (207 - 219 VGPRs), three for complete Y beyond
+    // (<= 229) and for the chained MASK instances (232: C3 with NA); the other MASK instances and the two-tile instances keep
+    // the two-buffer scheme below (deeper, their register allocation does what is described above and the build stops).
+#ifdef AQ_FORCE_DEEP_DB   // tools/isa_probe only: the deep scheme in instances the shipped build denies it (ISA study, never launched)
+#ifdef AQ_FORCE_DEEP_TT2
+    constexpr bool DEEP = (NTC >= 4);
+#else
+    constexpr bool DEEP = (TT == 1) && (NTC >= 4);
+#endif
+    constexpr int DB = !DEEP ? 1 : AQ_FORCE_DEEP_DB;
+#else
     constexpr bool DEEP = (TT == 1) && (NTC >= 4) && (!MASK || (SEG && NT <= 11));
     constexpr int DB = !DEEP ? 1 : (!MASK && NT <= 11) ? AQ_DEEP_TT1 : 3;
+#endif
     aq_v2 xb[DB][2], ab[DB][2];
     // Tile step t: U(t) = 4 TT MFMAs chained on Rr[.][t]; S(t-1) = 4 TT chained on acc, whose B operand Rr[.][t-1] was
     // finished a whole step earlier.  Loads, all issued at the START of a step: XU(t+1) (used one step later) and XA(t)

@@ -26,7 +26,7 @@ from collections import deque
 LABEL = re.compile(r"^(\.LBB\d+_\d+):")
 KERNEL = re.compile(r"^(_Z\w*aq_core_sweep_la_kernel\w*):")
 FUNC_END = re.compile(r"^\.Lfunc_end\d+:")
-VREG = re.compile(r"\bv(?:\[(\d+):(\d+)\]|(\d+))\b")
+VREG = re.compile(r"\bv(?:\[(\d+):(\d+)\]|(\d+)\b)")
 VMCNT = re.compile(r"vmcnt\((\d+)\)")
 VMEM = re.compile(r"^(global|scratch|buffer|flat|tbuffer)_(load|store|atomic)")
 BRANCH = re.compile(r"^s_(branch|cbranch_\w+)\s+(\.LBB\d+_\d+)")
