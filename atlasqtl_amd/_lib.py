@@ -44,6 +44,15 @@ class AqPrepInput(C.Structure):
                 ("device", C.c_int32)]
 
 
+class AqVbMultiOut(C.Structure):
+    _fields_ = [
+        ("beta_vb", dp), ("gam_vb", dp), ("mu_beta_vb", dp), ("theta_vb", dp), ("zeta_vb", dp), ("lam2_inv_vb", dp),
+        ("sig2_theta_vb", dp), ("tau_vb", dp), ("sig2_beta_vb", dp), ("elbo_it", ip), ("elbo_lb", dp), ("elbo_cap", C.c_int32),
+        ("n_elbo", C.c_int32), ("it", C.c_int32), ("converged", C.c_int32), ("lb_opt", C.c_double), ("diff_lb", C.c_double),
+        ("sig02_inv_vb", C.c_double), ("sig2_inv_vb", C.c_double), ("seconds", C.c_double), ("core_ms", C.c_double),
+    ]
+
+
 class AqVbStatus(C.Structure):
     _fields_ = [
         ("it", C.c_int32), ("converged", C.c_int32), ("lb_opt", C.c_double), ("diff_lb", C.c_double),
@@ -74,6 +83,8 @@ SYMBOLS = {
     "aq_vb_get_status": (C.c_int, [C.c_void_p, C.POINTER(AqVbStatus)]),
     "aq_vb_get_elbo_trace": (C.c_int32, [C.c_void_p, ip, dp, C.c_int32]),
     "aq_vb_get_result": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
+    "aq_vb_run_multi": (C.c_int, [C.POINTER(AqVbProblem), C.c_int32, ip, C.c_int32, C.POINTER(AqVbMultiOut)]),
+    "aq_vb_partition": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, ip, ip]),
     "aq_vb_get_residual": (C.c_int, [C.c_void_p, dp]),
     "aq_prepare_data": (C.c_int, [C.POINTER(AqPrepInput), C.POINTER(C.c_void_p)]),
     "aq_prep_info": (C.c_int, [C.c_void_p, ip, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), ip, dp, dp]),

@@ -94,6 +94,85 @@ def coreDualMisLoop(cp_X, cp_X_rm, cp_Y_X, gam_vb, log_Phi_theta_plus_zeta, log_
     check(rc, "coreDualMisLoop")
 
 
+def _build_problem(Y, X, prep, n, p, q, q_total, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval, debug, device,
+                   world, trait_offset, scheme, df, ext_main=None, ext_elbo=None):
+    """Fill an aq_vb_problem (include/atlasqtl_hip.h) from the reference's argument lists; returns (problem, objects to keep
+    alive while the library reads them)."""
+    pr = AqVbProblem()
+    pr.n, pr.p, pr.q, pr.q_total = n, p, q, q_total
+    keep = []
+
+    def vec(v, m, name):
+        a = np.asarray(v, dtype=np.float64)
+        a = np.full(m, float(a)) if a.ndim == 0 else np.ascontiguousarray(a)
+        if a.shape != (m,):
+            raise ValueError(f"{name} must have length {m}, got {a.shape}")
+        keep.append(a)
+        return as_dp(a)
+
+    def mat(v, shape, name):
+        a = np.asfortranarray(v, dtype=np.float64)
+        if a.shape != shape:
+            raise ValueError(f"{name} must have shape {shape}, got {a.shape}")
+        keep.append(a)
+        return as_dp(a)
+
+    keep += [X, Y]
+    if prep is None:
+        pr.X, pr.Y = as_dp(X), as_dp(Y)
+    else:
+        pr.X = C.cast(prep.x_ptr, _lib.dp)
+        if Y is prep.Y or (Y.shape == prep.Y.shape and np.array_equal(Y, prep.Y, equal_nan=True)):
+            pr.Y, pr.xy_on_device = C.cast(prep.y_ptr, _lib.dp), 3     # the centred Y that is already on the GPU
+        else:
+            pr.Y, pr.xy_on_device = as_dp(Y), 1                        # another Y (e.g. one trait shard of it) from the host
+    pr.A2_inv = float(list_hyper["A2_inv"]); pr.m0 = float(list_hyper["m0"])
+    pr.nu = float(list_hyper["nu"]); pr.rho = float(list_hyper["rho"]); pr.t02 = float(list_hyper["t02"])
+    pr.eta = vec(list_hyper["eta"], q, "eta"); pr.kappa = vec(list_hyper["kappa"], q, "kappa")
+    pr.n0 = vec(list_hyper["n0"], q, "n0")
+    g0, m0_ = list_init["gam_vb"], list_init["mu_beta_vb"]
+    if g0 is None and m0_ is None:
+        # the p x q initial values are drawn on the device (hyper_init.auto_set_init_(..., device_init=True))
+        pr.init_generate = 1
+        pr.init_seed = int(list_init["device_seed"]) & 0xFFFFFFFFFFFFFFFF
+        pr.init_gam_mean = float(list_init["device_gam_mean"])
+        pr.init_gam_sd = float(list_init["device_gam_sd"])
+        pr.init_on_device = 0
+    elif hasattr(g0, "data_ptr"):
+        # torch CUDA tensors holding the p x q matrices column-major, i.e. a contiguous (q, p) tensor
+        for tname, tt in (("gam_vb", g0), ("mu_beta_vb", m0_)):
+            if not (tt.is_cuda and tt.is_contiguous() and tuple(tt.shape) == (q, p) and str(tt.dtype) == "torch.float64"):
+                raise ValueError(f"{tname} on device must be a contiguous float64 CUDA tensor of shape (q, p) "
+                                 "(= p x q column-major)")
+        keep += [g0, m0_]
+        pr.gam_vb = C.cast(g0.data_ptr(), _lib.dp)
+        pr.mu_beta_vb = C.cast(m0_.data_ptr(), _lib.dp)
+        pr.init_on_device = 1
+    else:
+        pr.gam_vb = mat(g0, (p, q), "gam_vb")
+        pr.mu_beta_vb = mat(m0_, (p, q), "mu_beta_vb")
+        pr.init_on_device = 0
+    pr.sig02_inv_vb = float(list_init["sig02_inv_vb"])
+    pr.sig2_beta_vb = vec(list_init["sig2_beta_vb"], q, "sig2_beta_vb")
+    pr.sig2_theta_vb = vec(list_init["sig2_theta_vb"] if scheme != "global" else np.ones(p), p, "sig2_theta_vb")
+    pr.tau_vb = vec(list_init["tau_vb"], q, "tau_vb")
+    pr.theta_vb = vec(list_init["theta_vb"], p, "theta_vb")
+    pr.zeta_vb = vec(list_init["zeta_vb"], q, "zeta_vb")
+    pr.has_anneal = 0 if anneal is None else 1
+    if anneal is not None:
+        pr.anneal = (C.c_double * 3)(*[float(x) for x in anneal])
+    pr.tol = float(tol); pr.maxit = int(maxit)
+    pr.thinned_elbo_eval = 1 if thinned_elbo_eval else 0
+    pr.debug = 1 if debug else 0
+    pr.device = int(device); pr.world_size = int(world)
+    pr.trait_offset = int(trait_offset)
+    pr.scheme = {"global_local": 0, "global": 1}[scheme]
+    pr.df = int(df)
+    pr.ext_reduce_main = ext_main
+    pr.ext_reduce_elbo = ext_elbo
+    return pr, keep
+
+
 class VbRun:
     """A device-resident VB state (aq_vb_handle).  Keeps the host arrays alive while the
     library copies them, drives the aq_vb_advance protocol and fetches results."""
@@ -125,78 +204,8 @@ class VbRun:
             self._red = torch.zeros(int(L.aq_vb_reduce_len(p)), dtype=torch.float64, device=dev)
             self._ered = torch.zeros(8, dtype=torch.float64, device=dev)
             ext_main, ext_elbo = self._red.data_ptr(), self._ered.data_ptr()
-        pr = AqVbProblem()
-        pr.n, pr.p, pr.q, pr.q_total = n, p, q, self.q_total
-        keep = []
-
-        def vec(v, m, name):
-            a = np.asarray(v, dtype=np.float64)
-            a = np.full(m, float(a)) if a.ndim == 0 else np.ascontiguousarray(a)
-            if a.shape != (m,):
-                raise ValueError(f"{name} must have length {m}, got {a.shape}")
-            keep.append(a)
-            return as_dp(a)
-
-        def mat(v, shape, name):
-            a = np.asfortranarray(v, dtype=np.float64)
-            if a.shape != shape:
-                raise ValueError(f"{name} must have shape {shape}, got {a.shape}")
-            keep.append(a)
-            return as_dp(a)
-
-        keep += [X, Y]
-        if prep is None:
-            pr.X, pr.Y = as_dp(X), as_dp(Y)
-        else:
-            pr.X = C.cast(prep.x_ptr, _lib.dp)
-            if Y is prep.Y or (Y.shape == prep.Y.shape and np.array_equal(Y, prep.Y, equal_nan=True)):
-                pr.Y, pr.xy_on_device = C.cast(prep.y_ptr, _lib.dp), 3     # the centred Y that is already on the GPU
-            else:
-                pr.Y, pr.xy_on_device = as_dp(Y), 1                        # another Y (e.g. one trait shard of it) from the host
-        pr.A2_inv = float(list_hyper["A2_inv"]); pr.m0 = float(list_hyper["m0"])
-        pr.nu = float(list_hyper["nu"]); pr.rho = float(list_hyper["rho"]); pr.t02 = float(list_hyper["t02"])
-        pr.eta = vec(list_hyper["eta"], q, "eta"); pr.kappa = vec(list_hyper["kappa"], q, "kappa")
-        pr.n0 = vec(list_hyper["n0"], q, "n0")
-        g0, m0_ = list_init["gam_vb"], list_init["mu_beta_vb"]
-        if g0 is None and m0_ is None:
-            # the p x q initial values are drawn on the device (hyper_init.auto_set_init_(..., device_init=True))
-            pr.init_generate = 1
-            pr.init_seed = int(list_init["device_seed"]) & 0xFFFFFFFFFFFFFFFF
-            pr.init_gam_mean = float(list_init["device_gam_mean"])
-            pr.init_gam_sd = float(list_init["device_gam_sd"])
-            pr.init_on_device = 0
-        elif hasattr(g0, "data_ptr"):
-            # torch CUDA tensors holding the p x q matrices column-major, i.e. a contiguous (q, p) tensor
-            for tname, tt in (("gam_vb", g0), ("mu_beta_vb", m0_)):
-                if not (tt.is_cuda and tt.is_contiguous() and tuple(tt.shape) == (q, p) and str(tt.dtype) == "torch.float64"):
-                    raise ValueError(f"{tname} on device must be a contiguous float64 CUDA tensor of shape (q, p) "
-                                     "(= p x q column-major)")
-            keep += [g0, m0_]
-            pr.gam_vb = C.cast(g0.data_ptr(), _lib.dp)
-            pr.mu_beta_vb = C.cast(m0_.data_ptr(), _lib.dp)
-            pr.init_on_device = 1
-        else:
-            pr.gam_vb = mat(g0, (p, q), "gam_vb")
-            pr.mu_beta_vb = mat(m0_, (p, q), "mu_beta_vb")
-            pr.init_on_device = 0
-        pr.sig02_inv_vb = float(list_init["sig02_inv_vb"])
-        pr.sig2_beta_vb = vec(list_init["sig2_beta_vb"], q, "sig2_beta_vb")
-        pr.sig2_theta_vb = vec(list_init["sig2_theta_vb"] if scheme != "global" else np.ones(p), p, "sig2_theta_vb")
-        pr.tau_vb = vec(list_init["tau_vb"], q, "tau_vb")
-        pr.theta_vb = vec(list_init["theta_vb"], p, "theta_vb")
-        pr.zeta_vb = vec(list_init["zeta_vb"], q, "zeta_vb")
-        pr.has_anneal = 0 if anneal is None else 1
-        if anneal is not None:
-            pr.anneal = (C.c_double * 3)(*[float(x) for x in anneal])
-        pr.tol = float(tol); pr.maxit = int(maxit)
-        pr.thinned_elbo_eval = 1 if thinned_elbo_eval else 0
-        pr.debug = 1 if debug else 0
-        pr.device = int(device); pr.world_size = int(self.world)
-        pr.trait_offset = int(trait_offset)
-        pr.scheme = {"global_local": 0, "global": 1}[scheme]
-        pr.df = int(df)
-        pr.ext_reduce_main = ext_main
-        pr.ext_reduce_elbo = ext_elbo
+        pr, keep = _build_problem(Y, X, prep, n, p, q, self.q_total, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval,
+                                  debug, device, self.world, trait_offset, scheme, df, ext_main, ext_elbo)
         h = C.c_void_p()
         check(L.aq_vb_create(C.byref(pr), C.byref(h)), "aq_vb_create")
         self.h = h
@@ -405,6 +414,50 @@ class VbRun:
         if full_output:
             out.update(mu_beta_vb=mu, lam2_inv_vb=lam, sig2_theta_vb=s2t, tau_vb=tau, sig2_beta_vb=s2b)
         return out
+
+
+def vb_partition(q, n_parts):
+    """Trait ranges [(k0, k1)] of aq_vb_partition: whole 16-trait tiles per part."""
+    out = []
+    for r in range(n_parts):
+        k0, k1 = C.c_int32(), C.c_int32()
+        check(lib().aq_vb_partition(int(q), int(n_parts), r, C.byref(k0), C.byref(k1)), "aq_vb_partition")
+        out.append((k0.value, k1.value))
+    return out
+
+
+def run_multi(Y, X, list_hyper, list_init, anneal, tol, maxit, n_gpus, devices=None, transport=0, thinned_elbo_eval=True,
+              debug=True, scheme="global_local", df=1, full_output=True):
+    """aq_vb_run_multi: the whole run on n_gpus GPUs of this node from this one process (host threads + RCCL inside the
+    library; transport=1 stages the two small all-reduces through host memory and lets devices repeat).  Same result fields
+    as atlasqtl_global_local_core_."""
+    Y = np.asfortranarray(Y, dtype=np.float64)
+    X = np.asfortranarray(X, dtype=np.float64)
+    n, p = X.shape
+    q = Y.shape[1]
+    pr, keep = _build_problem(Y, X, None, n, p, q, q, list_hyper, list_init, anneal, tol, maxit, thinned_elbo_eval, debug,
+                              0, 1, 0, scheme, df)
+    out = _lib.AqVbMultiOut()
+    res = dict(beta_vb=np.zeros((p, q), order="F"), gam_vb=np.zeros((p, q), order="F"), theta_vb=np.zeros(p), zeta_vb=np.zeros(q))
+    if full_output:
+        res.update(mu_beta_vb=np.zeros((p, q), order="F"), lam2_inv_vb=np.zeros(p), sig2_theta_vb=np.zeros(p), tau_vb=np.zeros(q),
+                   sig2_beta_vb=np.zeros(q))
+    for k, v in res.items():
+        setattr(out, k, as_dp(v))
+    cap = 4096
+    its, lbs = np.zeros(cap, dtype=np.int32), np.zeros(cap)
+    out.elbo_it, out.elbo_lb, out.elbo_cap = as_ip(its), as_dp(lbs), cap
+    dv = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+    if dv is not None and dv.size != n_gpus:
+        raise ValueError("devices must list n_gpus ordinals")
+    check(lib().aq_vb_run_multi(C.byref(pr), int(n_gpus), as_ip(dv) if dv is not None else None, int(transport), C.byref(out)),
+          "aq_vb_run_multi")
+    ne = min(out.n_elbo, cap)
+    res.update(n=n, p=p, q=q, anneal=anneal, converged=bool(out.converged), it=int(out.it), maxit=maxit, tol=tol,
+               lb_opt=out.lb_opt, diff_lb=out.diff_lb, sig02_inv_vb=out.sig02_inv_vb, sig2_inv_vb=out.sig2_inv_vb,
+               elbo_trace=(its[:ne].copy(), lbs[:ne].copy()), seconds=out.seconds, core_ms=out.core_ms)
+    del keep
+    return res
 
 
 def atlasqtl_global_core_(Y, X, shr_fac_inv, anneal, df, tol, maxit, verbose, list_hyper, list_init, checkpoint_path=None,

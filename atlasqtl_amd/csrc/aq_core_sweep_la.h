@@ -156,11 +156,12 @@ constexpr int aq_req_issued(int D, int last, int t) {
 // is an agent-scope release (producer) / acquire (consumer) around done[k], and the wait is bounded.
 // MASK: Y with missing values (reference coreDualMisLoop, src/coreLoop.cpp:91-138): masked residual, per-trait Gram blocks and
 // per-entry sig2_beta_vb, the NA forms of the column sums (six rows).  One trait tile per workgroup only.
-template <int NT, int NT2, bool SEG, int TT, bool MASK = false>
+template <int NT, int NT2, bool SEG, int TT, bool MASK = false, int NT3_ = -1>
 __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCoreArgs a) {
   static_assert(!MASK || TT == 1, "the masked form keeps 16 per-trait Gram blocks in LDS: one trait tile per workgroup");
   constexpr int NWM = 6;                        // matrix waves: 0,1,2,4,5,6
-  constexpr int NT3 = aq_la_nt3(NT, NT2, TT);       // residual tiles of the recurrence wave (its matrix work follows its chain)
+  // residual tiles of the recurrence wave (its matrix work follows its chain): aq_la_nt3 unless the instance names its own count
+  constexpr int NT3 = NT3_ >= 0 ? NT3_ : aq_la_nt3(NT, NT2, TT);
   constexpr int NPS = NWM + (NT3 > 0 ? 1 : 0);  // partial S' slots
   constexpr int NTR = 16 * TT;                  // traits per workgroup
   constexpr int ENT = 256 * TT;                 // entries of one SNP block: [snp][trait]
@@ -212,7 +213,13 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   __shared__ double LB[2][ENT];        // slope b of Z
   __shared__ double Laa[2][ENT];       // intercept a of Z (Z = a + gam b, R/update_vb.R:217-234)
   __shared__ double LG[MASK ? 1 : 2][MASK ? 1 : 512];    // X_b'X_b as [16][32], upper 16 columns zero        (complete Y)
-  __shared__ double LGx[MASK ? 1 : 2][MASK ? 1 : 256];   // X_b'X_{b-1}  [j][i]                              (complete Y)
+  // Complete Y, where the cross-block correction X_b'X_{b-1} delta_{b-1} comes from: with two trait tiles per workgroup the matrix
+  // SIMDs are the bound and the helper wave forms the product after each chain (Lcx); with ONE tile per workgroup (the trait
+  // shards of a multi-GPU run, small q: the chain is the critical path) it is accumulated INSIDE the chain of block b-1, one
+  // column of X_b'X_{b-1} per step as that step's delta appears -- complete the moment that chain ends (CXC).  The chain of
+  // block b-1 then needs block b's cross Gram: three buffers, block m in LGx[m % 3], staged a block earlier.
+  constexpr bool CXC = (TT == 1) && !MASK;
+  __shared__ double LGx[MASK ? 1 : 3][MASK ? 1 : 256];   // X_b'X_{b-1}  [j][i]                              (complete Y)
   // MASK: the traits' own blocks, written by LDS-DMA.  Diagonal block: lower triangle [i (i + 1) / 2 + j][trait], by block
   // parity; cross block [j][i][trait], ONE buffer (released by the recurrence wave through Fl[13] as soon as the correction
   // at the start of a chain has read it).  Per-entry constants of the chain.
@@ -220,14 +227,17 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   __shared__ double LGxk[MASK ? 4096 : 1];
   __shared__ double Lcoef[2][MASK ? ENT : 1], LK[2][MASK ? ENT : 1], Ls2[2][MASK ? ENT : 1], Lls2[2][MASK ? ENT : 1], Lxn[2][MASK ? ENT : 1];
   __shared__ double Lgam[2][ENT], Lmu[2][ENT], Ldel[2][ENT];
+  __shared__ double Lcx[MASK ? 1 : ENT];   // complete Y: X_b'X_{b-1} delta_{b-1} of the block whose chain comes next, from the helper wave
+  __shared__ double Ldum[ENT];         // where the recurrence wave's lanes of row groups > 0 put their (identical) gam, mu, delta
   __shared__ double Stot[(SEG || TT == 2) ? 1 : 2][(SEG || TT == 2) ? 1 : ENT];   // sample split: S' of a block summed over all parts (from the helper wave)
+  __shared__ double Lpt[AQ_PT_LEN];    // the probit tables (aq_probit_tab.h), [function][coefficient][interval]: 6.2 KB
   __shared__ double Lred[6][64];       // the helper lanes' column sums [row group][trait], added up per trait at the end
   __shared__ double Lrn[NPS * 4][NTR];
   // Point-to-point progress counters instead of a workgroup barrier per phase: Fl[0..5] = number of SNP blocks whose
   // partial S' matrix wave m has written, Fl[6] = blocks the recurrence wave has finished, Fl[7] = blocks the helper
   // wave has staged, Fl[8..10] = phases that matrix wave 0..2 has carried past its stagger tile (its SIMD partner 4..6
   // starts the phase then), Fl[11] = phases the recurrence wave's own matrix work has finished (init mode: the helper may
-  // then reuse a beta buffer), Fl[13] = (MASK) chains that have read their cross blocks, Fl[14] = (sample split) blocks whose
+  // then reuse a beta buffer), Fl[12] = (complete Y) blocks whose cross-block correction the helper wave has put into Lcx, Fl[13] = (MASK) chains that have read their cross blocks, Fl[14] = (sample split) blocks whose
   // S' the helper wave has exchanged with the other parts.  Each wave waits only for what it really reads, so the matrix waves -- the critical path --
   // never stop at a barrier.  LDS operations of a wave execute in order and the LDS is one pipeline per CU, so
   // "data stores; s_waitcnt lgkmcnt(0); counter store" on one side and "counter load ... ; data loads" on the other are
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   // timeline of workgroup 0, phases 64 .. 95: slot k of (wave, phase) <- cycle counter (behind the per-wave counters in a.dbg)
   auto tl_mark = [&](int i, int k) __attribute__((always_inline)) {
     if (a.dbg && blockIdx.x == 0 && i >= 64 && i < 96 && lane == 0)
-      a.dbg[(size_t)gridDim.x * 24 + ((size_t)w * 32 + (i - 64)) * 4 + k] = __builtin_readcyclecounter();
+      a.dbg[(size_t)gridDim.x * 24 + ((size_t)w * 32 + (i - 64)) * 8 + k] = __builtin_readcyclecounter();
   };
 #else
   auto tl_mark = [&](int, int) __attribute__((always_inline)) {};
@@ -271,6 +281,8 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   double sig2b_k = 1.0;
   if (helper) {
     sig2b_k = a.sig2b[ktrait];
+    if (a.mode != 1)
+      for (int e = lane; e < AQ_PT_LEN; e += 64) Lpt[e] = aq_pt_dev[e];
 #pragma unroll
     for (int r = 0; r < RPG; r++) {
       const int e = lane + 64 * r;
@@ -655,8 +667,8 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     if (a.mode != 1) {   // (init mode: the helper wave hands beta to the matrix waves, nothing to do here)
       const double rc_coef = MASK ? 0.0 : a.coef[ktrait];
       const double rc_cinv2s = MASK ? 0.0 : a.c * a.inv2s[ktrait];
-      const double rc_cst = MASK ? 0.0 : a.cst[ktrait];
       const double rc_K = rc_coef * rc_coef * rc_cinv2s;   // keeps mu off the dependency chain of the recursion
+      double cxn[CXC ? RPG : 1];   // (CXC) the next block's cross-block correction, built up by the chain that is running
       auto chain_block = [&](int b) __attribute__((always_inline)) {
         const int par = b & 1;
         // ---- SNP block b.  lane = (hg, ht): ht = trait, hg one of NG row groups -------------------------------------
@@ -687,6 +699,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
             Sown[r] = sv;
           }
         }
+        tl_mark(need, 4);                  // (diag) partial S' complete and summed
         // cross-block correction X_b'X_{b-1} delta_{b-1} of this group's rows (a segment starts from a complete residual);
         // MASK: with the trait's own cross block X_b' diag(mis_k) X_{b-1}.  It does not depend on S': with the sample split it
         // is computed while the partial sums travel.
@@ -695,22 +708,38 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         double cxs[(!SEG && TT == 1) ? RPG : 1];
         auto correction = [&](auto subc) __attribute__((always_inline)) {
           constexpr bool sub = decltype(subc)::value;
-          if (b > seg_b0) {
+          if constexpr (CXC) {
+            // one tile per workgroup: accumulated by the previous chain, in registers
+#pragma unroll
+            for (int r = 0; r < RPG; r++) {
+              const double cx = b > seg_b0 ? cxn[r] : 0.0;
+              if constexpr (sub) Sown[r] -= cx;
+              else cxs[r] = cx;
+            }
+          } else if constexpr (!MASK) {
+            // complete Y: the helper wave formed the 16 x 16 product right after the previous chain (Fl[12]); here it is 8 reads
+            if (b > seg_b0) {
+              wait_ge(12, need);
+#pragma unroll
+              for (int r = 0; r < RPG; r++) {
+                const double cx = Lcx[lane + 64 * r];
+                if constexpr (sub) Sown[r] -= cx;
+                else cxs[r] = cx;
+              }
+            } else if constexpr (!sub) {
+#pragma unroll
+              for (int r = 0; r < RPG; r++) cxs[r] = 0.0;
+            }
+          } else if (b > seg_b0) {
             double dlp[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) dlp[i] = Ldel[par ^ 1][i * NTR + ht];
 #pragma unroll
             for (int r = 0; r < RPG; r++) {
               double cx = 0.0;
-              if constexpr (MASK) {
-                const double *gx = &LGxk[((hg + NG * r) * 16) * 16 + ht];
+              const double *gx = &LGxk[((hg + NG * r) * 16) * 16 + ht];
 #pragma unroll
-                for (int i = 0; i < 16; i++) cx += gx[i * 16] * dlp[i];
-              } else {
-                const double *gx = &LGx[par][(hg + NG * r) * 16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) cx += gx[i] * dlp[i];
-              }
+              for (int i = 0; i < 16; i++) cx += gx[i * 16] * dlp[i];
               if constexpr (sub) Sown[r] -= cx;
               else cxs[r] = cx;
             }
@@ -729,7 +758,22 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           }
         }
         if (!corrected) correction(std::true_type{});
+        tl_mark(need, 5);                  // (diag) correction applied: the 16 steps start
         double sb = __shfl(Sown[0], ht, 64);     // S of SNP 0 (group 0) to every group
+        // The 16 steps.  What one step costs is its dependent chain s -> x -> sigmoid -> delta (about 26 fp64 operations) --
+        // provided nothing else sits on it.  Two things did (ISA of round 2: the ds_bpermute that fetches the next SNP's S from
+        // its owner group was issued at the END of a step, so every step also paid an LDS round trip; and the three stores of
+        // gam, mu, delta sat behind an exec-mask branch):
+        //   * the S of SNP j+2 is requested at the tail of step j, right after delta_j has been applied to the one register that
+        //     holds it, and pinned there (sched_barrier): its round trip runs under the whole of step j+1;
+        //   * every lane stores -- the lanes of the other row groups into a scratch area of the same shape (no branch).
+        double s_nx = __shfl(Sown[1 / NG], (1 % NG) * NTR + ht, 64);   // S of SNP 1, no in-block update yet
+        typedef __attribute__((address_space(3))) double aq_lds_double;
+        const bool wsel = lane < NTR;
+        aq_lds_double *wdum = (aq_lds_double *)Ldum + ht;
+        aq_lds_double *wgam = wsel ? (aq_lds_double *)Lgam[par] + ht : wdum;
+        aq_lds_double *wmu = wsel ? (aq_lds_double *)Lmu[par] + ht : wdum;
+        aq_lds_double *wdel = wsel ? (aq_lds_double *)Ldel[par] + ht : wdum;
         if constexpr (MASK) {
           signal(13, b - seg_b0 + 1);              // the single cross-block buffer is free for block b+1
           // ---- the same chain with the trait's own diagonal block (lower triangle in LGk) and per-entry sig2_beta_vb
@@ -741,52 +785,79 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           double m1o = Lm1[par][ht], cA = LA[par][ht], cf = Lcoef[par][ht], ci = LK[par][ht], dj = LGk[ht];
 #pragma unroll
           for (int j = 0; j < 16; j++) {
-            const int jn = (j + 1) & 15;
+            const int jn = (j + 1) & 15, j2 = j + 2;
             const int en = jn * NTR + ht;
             double m1o_n = Lm1[par][en], cA_n = LA[par][en], cf_n = Lcoef[par][en], ci_n = LK[par][en];
             double d_n = LGk[(jn * (jn + 1) / 2 + jn) * 16 + ht];
             const double g_next = LGk[(j < 15 ? (jn * (jn + 1) / 2 + j) : 0) * 16 + ht];   // G^(k)[j+1][j]
-            const double s_next = __shfl(Sown[jn / NG], (jn % NG) * NTR + ht, 64);
+            const int r2 = (j2 & 15) / NG;
+            double gl[RPG];                                   // this group's column j of G^(k), for the in-block update below
+#pragma unroll
+            for (int r = (j / NG); r < RPG; r++) gl[r] = LGk[(rtri[r] + (rrow[r] < j ? rrow[r] : j)) * 16 + ht];
+            __builtin_amdgcn_sched_barrier(0);                // every LDS read that does not depend on this step's delta is on its way
             double s = sb + m1o * dj;                         // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1 (cp_X - cp_X_rm_k)(j,j))   :121
             double mu = cf * s;                               // :125
             double x = fma(-(s * s), ci, cA);                 // :127-129 with mu^2 = coef^2 s^2 (keeps mu off the chain)
             double gm = aq_sigmoid_neg_fast(x);
             double dl = gm * mu - m1o;                        // m1 - m1_old   :130
-            sb = s_next - g_next * dl;
-            // in-block part of :132, this group's rows (rows <= j are consumed: any finite factor will do for them)
-#pragma unroll
-            for (int r = (j / NG); r < RPG; r++) Sown[r] -= LGk[(rtri[r] + (rrow[r] < j ? rrow[r] : j)) * 16 + ht] * dl;
-            if (lane < NTR) {
-              Lgam[par][j * NTR + ht] = gm;
-              Lmu[par][j * NTR + ht] = mu;
-              Ldel[par][j * NTR + ht] = dl;
+            sb = s_nx - g_next * dl;                          // S of SNP j+1, complete
+            // in-block part of :132, this group's rows (rows <= j are consumed: any finite factor will do for them): first
+            // the register that holds SNP j+2, whose S goes on its way to every group at once
+            auto upd = [&](int r) __attribute__((always_inline)) { Sown[r] -= gl[r] * dl; };
+            if (j2 < 16) {
+              Sown[r2] -= gl[r2] * dl;
+              s_nx = __shfl(Sown[r2], (j2 % NG) * NTR + ht, 64);
+              __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int r = (j / NG); r < RPG; r++)
+              if (!(j2 < 16 && r == j2 / NG)) upd(r);
+            wgam[j * NTR] = gm;
+            wmu[j * NTR] = mu;
+            wdel[j * NTR] = dl;
             m1o = m1o_n; cA = cA_n; cf = cf_n; ci = ci_n; dj = d_n;
           }
         } else {
-        double m1o = Lm1[par][ht], cA = a.c * (LA[par][ht] + rc_cst), dj = LG[par][0];
+        double m1o = Lm1[par][ht], cA = LA[par][ht], dj = LG[par][0];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-          const int jn = (j + 1) & 15;
-          double m1o_n = Lm1[par][jn * NTR + ht], cA_n = a.c * (LA[par][jn * NTR + ht] + rc_cst), d_n = LG[par][jn * 33];
-          // the next SNP's S is fetched from its owner group BEFORE this step's delta is known (off the chain) ...
+          const int jn = (j + 1) & 15, j2 = j + 2;
+          double m1o_n = Lm1[par][jn * NTR + ht], cA_n = LA[par][jn * NTR + ht], d_n = LG[par][jn * 33];   // (LA holds c (A + cst))
           const double g_next = LG[par][j * 32 + jn];
-          const double s_next = __shfl(Sown[jn / NG], (jn % NG) * NTR + ht, 64);
+          double gl[RPG];                                   // this group's column j of G, for the in-block update below
+#pragma unroll
+          for (int r = (j / NG); r < RPG; r++) gl[r] = LG[par][j * 32 + hg + NG * r];
+          double gxn[CXC ? RPG : 1];                        // (CXC) column j of the NEXT block's X_{b+1}'X_b, this group's rows
+          if constexpr (CXC) {
+#pragma unroll
+            for (int r = 0; r < RPG; r++) gxn[r] = LGx[(b + 1) % 3][(hg + NG * r) * 16 + j];
+          }
+          __builtin_amdgcn_sched_barrier(0);                // every LDS read that does not depend on this step's delta is on its way
           double s = sb + m1o * dj;                         // cp_Y_X(k,j) - (cp_betaX_X(j,k) - m1*cp_X(j,j))   :71
           double mu = rc_coef * s;                          // :73
           double x = fma(-(s * s), rc_K, cA);               // c*(log(1-Phi) - log Phi - mu^2/(2 sig2) + cst), mu^2 = coef^2 s^2   :75-77
           double gm = aq_sigmoid_neg_fast(x);
           double dl = gm * mu - m1o;                        // m1 - m1_old, m1 = gam*mu   :79
-          sb = s_next - g_next * dl;                        // ... and completed with this step's update: one FMA on the chain
-          // in-block part of :81, this group's rows (rows <= j are already consumed: updating them is harmless)
-#pragma unroll
-          for (int r = (j / NG); r < RPG; r++) Sown[r] -= LG[par][j * 32 + hg + NG * r] * dl;
-          if (lane < NTR) {
-            Lgam[par][j * NTR + ht] = gm;
-            Lmu[par][j * NTR + ht] = mu;
-            Ldel[par][j * NTR + ht] = dl;
+          sb = s_nx - g_next * dl;                          // S of SNP j+1 completed with this step's update: one FMA on the chain
+          // in-block part of :81, this group's rows (rows <= j are already consumed: updating them is harmless): first the
+          // register that holds SNP j+2, whose S goes on its way to every group at once
+          if (j2 < 16) {
+            Sown[j2 / NG] -= gl[j2 / NG] * dl;
+            s_nx = __shfl(Sown[j2 / NG], (j2 % NG) * NTR + ht, 64);
+            __builtin_amdgcn_sched_barrier(0);
           }
+#pragma unroll
+          for (int r = (j / NG); r < RPG; r++)
+            if (!(j2 < 16 && r == j2 / NG)) Sown[r] -= gl[r] * dl;
+          if constexpr (CXC) {
+#pragma unroll
+            for (int r = 0; r < RPG; r++) cxn[r] = (j == 0 ? 0.0 : cxn[r]) + gxn[r] * dl;
+          }
+          wgam[j * NTR] = gm;
+          wmu[j * NTR] = mu;
+          wdel[j * NTR] = dl;
           m1o = m1o_n; cA = cA_n; dj = d_n;
+          if (j == 7) tl_mark(need, 6);    // (diag) half of the steps
         }
         }
         signal(6, b - seg_b0 + 1);   // delta, gam, mu of block b are in LDS
@@ -811,10 +882,27 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     // This wave shares its SIMD only with the recurrence wave, whose dependent chain leaves the VALU mostly idle.
     const size_t tbase = (size_t)(tile0 + (ht >> 4)) * a.p_pad * 16 + (ht & 15);   // this lane's tile and column
     const double zk = a.zeta[ktrait];
+    typedef __attribute__((address_space(3))) const double aq_lds_cdouble;
+    aq_lds_cdouble *ptab = (aq_lds_cdouble *)(__attribute__((address_space(3))) double *)Lpt;
+    const double inv_sqrt_c = 1.0 / a.sqrt_c;
+    const double cst_k = MASK ? 0.0 : a.cst[ktrait];                                 // -(log_tau + log_sig2_inv + log sig2_beta) / 2
     double th[RPG];   // theta of the block to be staged next, loaded a phase earlier so that the arithmetic never waits for HBM
     auto theta_load = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < RPG; r++) th[r] = a.theta[16 * b + hg + NG * r];
+    };
+    // complete Y: gam and mu of the block to be staged next, requested together with its theta a phase ahead; stage() turns them
+    // into m1 = gam mu first thing, so that their registers are free again while the probit tables are evaluated
+    double pg[MASK ? 1 : RPG], pm[MASK ? 1 : RPG];
+    auto gm_load = [&](int b) __attribute__((always_inline)) {
+      if constexpr (!MASK) {
+#pragma unroll
+        for (int r = 0; r < RPG; r++) {
+          const size_t off = tbase + (size_t)(16 * b + hg + NG * r) * 16;
+          pg[r] = a.gam[off];
+          pm[r] = a.mu[off];
+        }
+      }
     };
     // MASK: per-trait constants of the NA forms (src/coreLoop.cpp:108, R/update_vb.R:45) and this block's slice of GK
     const double tau_k = MASK ? a.tau[ktrait] : 1.0;
@@ -864,38 +952,26 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       if (b_next < seg_b1) { pre_load(b_next); theta_load(b_next); }
     };
     auto stage = [&](int b, int par) __attribute__((always_inline)) {
-      double st_g[RPG], st_m[RPG], st_G[4], st_Gx[4], st_xn[RPG];
+      double st_G[4], st_Gx[4], st_xn[MASK ? RPG : 1];
       if constexpr (MASK) {
 #pragma unroll
-        for (int r = 0; r < RPG; r++) { st_g[r] = sv_g[r]; st_m[r] = sv_m[r]; st_xn[r] = sv_xn[r]; }
+        for (int r = 0; r < RPG; r++) { Lm1[par][lane + 64 * r] = sv_g[r] * sv_m[r]; st_xn[r] = sv_xn[r]; }
       } else {
 #pragma unroll
-        for (int r = 0; r < RPG; r++) {
-          const size_t off = tbase + (size_t)(16 * b + hg + NG * r) * 16;
-          st_g[r] = a.gam[off];
-          st_m[r] = a.mu[off];
-        }
+        for (int r = 0; r < RPG; r++) Lm1[par][lane + 64 * r] = pg[r] * pm[r];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           st_G[r] = a.G[(size_t)b * 256 + lane + 64 * r];
-          st_Gx[r] = a.Gx[(size_t)b * 256 + lane + 64 * r];
+          // the cross Gram block that goes with this staging: block b's own, or (CXC) block b+1's, which the chain of block b reads
+          const int bx = CXC ? (b + 1 < a.nb ? b + 1 : b) : b;
+          st_Gx[r] = a.Gx[(size_t)bx * 256 + lane + 64 * r];
         }
       }
-#pragma unroll
-      for (int r = 0; r < RPG; r++) {
+      // A(u), the slope b = imr1 - imr0 and the intercept a = u + imr0 of Z (at U = sqrt(c) u, over sqrt(c), when annealing:
+      // R/update_vb.R:219-233), u = theta_j + zeta_k, for the RPG entries of this lane.
+      auto emitA = [&](int r, double A) __attribute__((always_inline)) {
         const int j = 16 * b + hg + NG * r, e = lane + 64 * r;
-        const double u = (MASK ? sv_th[r] : th[r]) + zk;
-        double A, imr1, imr0, ee;
-        aq_probit_A_imr(u, &A, &imr1, &imr0, &ee);
-        if (!a.c_is_one) {
-          double Ac;
-          aq_probit_A_imr(a.sqrt_c * u, &Ac, &imr1, &imr0, &ee);
-          imr1 /= a.sqrt_c;
-          imr0 /= a.sqrt_c;
-        }
         const bool valid = kvalid && j < a.p;
-        LB[par][e] = valid ? imr1 - imr0 : 0.0;
-        Laa[par][e] = valid ? u + imr0 : 0.0;
         if constexpr (MASK) {
           const double is2 = a.c * (st_xn[r] + sig2_inv_h) * tau_k;            // update_sig2_beta_vb_ with X_norm_sq, R/update_vb.R:45
           const double s2 = aq_recip_pos(is2);
@@ -908,11 +984,109 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           Lls2[par][e] = ls2;
           Lxn[par][e] = st_xn[r];
         } else {
-          LA[par][e] = valid ? A : 0.0;
+          LA[par][e] = a.c * ((valid ? A : 0.0) + cst_k);                        // c (log(1-Phi) - log Phi + cst), src/coreLoop.cpp:75-77
+        }
+      };
+      auto emitZ = [&](int r, double zb, double za) __attribute__((always_inline)) {
+        const int j = 16 * b + hg + NG * r, e = lane + 64 * r;
+        const bool valid = kvalid && j < a.p;
+        LB[par][e] = valid ? zb : 0.0;
+        Laa[par][e] = valid ? za : 0.0;
+      };
+      // the same three probit-dependent fields again, for a run-time r (second pass of a block with lanes outside the tables)
+      auto emit2 = [&](int r, double A, double zb, double za) __attribute__((always_inline)) {
+        const int j = 16 * b + hg + NG * r, e = lane + 64 * r;
+        const bool valid = kvalid && j < a.p;
+        LB[par][e] = valid ? zb : 0.0;
+        Laa[par][e] = valid ? za : 0.0;
+        if constexpr (MASK) LA[par][e] = a.c * ((valid ? A : 0.0) - 0.5 * Lls2[par][e] + cstna_k);
+        else LA[par][e] = a.c * ((valid ? A : 0.0) + cst_k);
+      };
+      double uu[RPG];
+      bool inr = true;
+#pragma unroll
+      for (int r = 0; r < RPG; r++) {
+        uu[r] = (MASK ? sv_th[r] : th[r]) + zk;
+        inr = inr && fabs(uu[r]) < AQ_PT_R && fabs(a.sqrt_c * uu[r]) < AQ_PT_R;   // (false for NaN)
+      }
+      {
+        // Tables (aq_probit_tab.h: A, b, d as piecewise polynomials of degree AQ_PT_DEG; coefficient k of function f on interval
+        // i at Lpt[(f (DEG+1) + k) NI + i]).  The coefficients of an entry are a gather from LDS, and a wave that waits for
+        // them can do nothing else: the reads of entry r+1 are issued BEFORE the arithmetic of entry r (two register sets), so
+        // that the Horner chains never wait for the LDS round trip.  Two passes -- A at u, then b and d at sqrt(c) u -- keep
+        // the register sets at 2 x 22 and 2 x 44 VGPRs.
+        constexpr int NC = AQ_PT_DEG + 1, S = AQ_PT_NI, F = NC * S;
+        // interval and local variable of v = |x|: i = floor(2 v) (clamped: a lane outside the tables reads the last interval
+        // and is redone below), x = 2 (2 v - i) - 1
+        auto locate = [&](double x, double *xloc) __attribute__((always_inline)) {
+          const double t = fmin(fabs(x) * (1.0 / AQ_PT_W), AQ_PT_NI - 0.5);
+          const int i = (int)t;
+          *xloc = fma(2.0, t - (double)i, -1.0);
+          return ptab + i;
+        };
+        {
+          double co[2][NC], xl[2];
+          auto fetch = [&](int r, auto setc) __attribute__((always_inline)) {
+            constexpr int set = decltype(setc)::value;
+            aq_lds_cdouble *pp = locate(uu[r], &xl[set]);
+#pragma unroll
+            for (int k = 0; k < NC; k++) co[set][k] = pp[k * S];
+          };
+          fetch(0, std::integral_constant<int, 0>{});
+          aq_static_for<RPG>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value, set = r & 1;
+            if constexpr (r + 1 < RPG) fetch(r + 1, std::integral_constant<int, (r + 1) & 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            double pa = co[set][NC - 1];
+#pragma unroll
+            for (int k = NC - 2; k >= 0; k--) pa = fma(pa, xl[set], co[set][k]);
+            emitA(r, uu[r] < 0.0 ? -pa : pa);                            // A is odd
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        {
+          double co[2][2 * NC], xl[2];
+          auto fetch = [&](int r, auto setc) __attribute__((always_inline)) {
+            constexpr int set = decltype(setc)::value;
+            aq_lds_cdouble *pp = locate(a.sqrt_c * uu[r], &xl[set]);
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+              co[set][k] = pp[F + k * S];
+              co[set][NC + k] = pp[2 * F + k * S];
+            }
+          };
+          fetch(0, std::integral_constant<int, 0>{});
+          aq_static_for<RPG>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value, set = r & 1;
+            if constexpr (r + 1 < RPG) fetch(r + 1, std::integral_constant<int, (r + 1) & 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            double pb = co[set][NC - 1], pd = co[set][2 * NC - 1];
+#pragma unroll
+            for (int k = NC - 2; k >= 0; k--) {
+              pb = fma(pb, xl[set], co[set][k]);
+              pd = fma(pd, xl[set], co[set][NC + k]);
+            }
+            const double d = uu[r] < 0.0 ? -pd : pd;                     // d is odd, b is even
+            // imr0 = -M(U) = -(b + d) / 2:  a = u + imr0 / sqrt(c),  slope = b / sqrt(c)
+            emitZ(r, pb * inv_sqrt_c, uu[r] - 0.5 * inv_sqrt_c * (pb + d));
+            __builtin_amdgcn_sched_barrier(0);
+          });
         }
       }
+      if (__builtin_expect(!__all(inr), 0)) {
+        // some lane of the wave is outside the tables (|u| >= 12): the block is done again entry by entry with the tail series
+        // of aq_special.h for those lanes (aq_probit_tab_eval picks per lane)
+#pragma unroll 1
+        for (int r = 0; r < RPG; r++) {
+          double ur = uu[0];
 #pragma unroll
-      for (int r = 0; r < RPG; r++) Lm1[par][lane + 64 * r] = st_g[r] * st_m[r];
+          for (int k = 1; k < RPG; k++) ur = (r == k) ? uu[k] : ur;       // (no dynamically indexed register arrays)
+          double A, bM, dM, dummy;
+          aq_probit_tab_eval<1>(ur, ptab, &A, &dummy, &dummy);
+          aq_probit_tab_eval<2>(a.sqrt_c * ur, ptab, &dummy, &bM, &dM);
+          emit2(r, A, bM * inv_sqrt_c, ur - 0.5 * inv_sqrt_c * (bM + dM));
+        }
+      }
       if constexpr (MASK) {
 #ifdef AQ_DIAG_TIME
         const long long t_dma = __builtin_readcyclecounter();
@@ -926,7 +1100,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         for (int r = 0; r < 4; r++) {
           const int e = lane + 64 * r;
           LG[par][(e >> 4) * 32 + (e & 15)] = st_G[r];
-          LGx[par][e] = st_Gx[r];
+          LGx[CXC ? (b + 1) % 3 : par][e] = st_Gx[r];
         }
       }
     };
@@ -1039,11 +1213,12 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         }
       };
       theta_load(seg_b0);
+      gm_load(seg_b0);
       if constexpr (MASK) { pre_load(seg_b0); stage_dma(seg_b0, seg_b0 & 1, seg_b0 + 1); }
       stage(seg_b0, seg_b0 & 1);
       signal(7, 1);
       if constexpr (!SEG && TT == 1) { if (C > 1 && a.xhelper) exchange(seg_b0); }
-      if constexpr (!MASK) { if (seg_b0 + 1 < seg_b1) theta_load(seg_b0 + 1); }
+      if constexpr (!MASK) { if (seg_b0 + 1 < seg_b1) { theta_load(seg_b0 + 1); gm_load(seg_b0 + 1); } }
       for (int b = seg_b0; b < seg_b1; b++) {
         const int par = b & 1;
         if constexpr (MASK) {
@@ -1053,13 +1228,32 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
         }
         // block b-1 must be through the recurrence: its gam / mu are read here, and the parity buffers about to be
         // overwritten with block b+1 are the ones it read
-        if (b > seg_b0) { wait_ge(6, b - seg_b0); finalize(b - 1, par ^ 1); }
+        if (b > seg_b0) {
+          wait_ge(6, b - seg_b0);
+          if constexpr (!MASK && !CXC) {
+            // cross-block correction X_b'X_{b-1} delta_{b-1} of block b for the recurrence wave (a 16 x 16 by 16 x NTR product: 128
+            // multiply-adds and 144 LDS reads per lane that would otherwise sit between "S' complete" and the first chain step)
+            double dlp[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) dlp[i] = Ldel[par ^ 1][i * NTR + ht];
+#pragma unroll
+            for (int r = 0; r < RPG; r++) {
+              double cx = 0.0;
+              const double *gx = &LGx[par][(hg + NG * r) * 16];
+#pragma unroll
+              for (int i = 0; i < 16; i++) cx += gx[i] * dlp[i];
+              Lcx[lane + 64 * r] = cx;
+            }
+            signal(12, b - seg_b0 + 1);
+          }
+          finalize(b - 1, par ^ 1);
+        }
         if (b + 1 < seg_b1) {
           stage(b + 1, par ^ 1);
           signal(7, b - seg_b0 + 2);
           if constexpr (!SEG && TT == 1) { if (C > 1 && a.xhelper) exchange(b + 1); }
           if (a.xtouch && b + 2 < seg_b1) x_touch(b + 2, b);
-          if constexpr (!MASK) { if (b + 2 < seg_b1) theta_load(b + 2); }
+          if constexpr (!MASK) { if (b + 2 < seg_b1) { theta_load(b + 2); gm_load(b + 2); } }
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(xt[0]), "+v"(xt[1]), "+v"(xt[2]), "+v"(xt[3]), "+v"(xt[4]), "+v"(xt[5]), "+v"(xt[6]), "+v"(xt[7]));

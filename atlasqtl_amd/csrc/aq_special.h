@@ -25,6 +25,7 @@
 #define AQ_SQRT_2_OVER_PI 0.79788456080286535587989211986876
 #define AQ_INV_SQRT_2PI 0.39894228040143267793994605993438
 #include "aq_erfcx_coef.h"
+#include "aq_probit_tab.h"
 
 // log Phi(x).  x > 0: log1p(-erfc(x/sqrt2)/2); -37 < x <= 0: log(erfc(-x/sqrt2)/2)
 // (erfc keeps full relative accuracy in its tail until it underflows near 26.5);
@@ -179,6 +180,91 @@ AQ_HD void aq_probit_A_imr(double x, double *A, double *imr1, double *imr0, doub
   *imr1 = i1;
   *imr0 = i0;
   *e_out = e;
+}
+
+// The same three quantities from tables (aq_probit_tab.h, tools/gen_probit_tab.py): A, b = imr1 - imr0 and imr0 are smooth
+// functions of ONE variable, so on |x| < AQ_PT_R they are piecewise polynomials of degree AQ_PT_DEG in the local variable of
+// an interval of width 1/2 -- three Horner chains (~45 fp64 operations) instead of the ~200 of erfcx + exp + log + reciprocal.
+//   A(x) odd;  b(x) = M(x) + M(-x) even;  d(x) = M(x) - M(-x) odd, M = phi / (1 - Phi);  imr0 = -M(x) = -(b + d) / 2.
+// `tab` = the table as [3][AQ_PT_DEG + 1][AQ_PT_NI] (the kernels pass their LDS copy: coefficient-major, lanes in different
+// intervals hit different banks).  The reference's clamps (R/utils.R:180-181, 188-189: imr1 >= -x, imr0 <= -x) hold strictly
+// for the exact functions (M(x) > x) and by a margin >= 1/(2 R) inside the tables.
+#if defined(__HIPCC__)
+__device__ static const double aq_pt_dev[AQ_PT_LEN] = {AQ_PT_VALUES};
+#endif
+static const double aq_pt_host[AQ_PT_LEN] = {AQ_PT_VALUES};
+AQ_HD const double *aq_pt_table() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return aq_pt_dev;
+#else
+  return aq_pt_host;
+#endif
+}
+// Beyond the tables, |x| >= AQ_PT_R = 12: the far tail is Phi(-v) = phi(v) / v * S(1 / v^2) with the asymptotic series
+// S(w) = sum_n (-1)^n (2n - 1)!! w^n, whose terms still fall until n ~ v^2 / 2 = 72: cut after n = 14 the error is below
+// 2e-17 relative at v = 12 and shrinks with v.  The near tail 1 - Phi(-v) differs from 1 by less than 2e-33, so
+//   M(v) = v / S,   M(-v) = phi(v) / Phi(v) < 3e-32 (nothing next to M(v) >= 12: taken as 0),
+//   A = -+ (v^2 / 2 + log v + log sqrt(2 pi) - log S).
+// No exponential, a handful of constants: this is what the sweep kernel carries for the rare block that leaves the tables.
+AQ_HD void aq_probit_tail(double x, double *A, double *b, double *d) {
+  const double v = fabs(x);
+  const double w = 1.0 / (v * v);
+  double S = 213458046676875.0;
+  S = fma(S, w, -7905853580625.0);
+  S = fma(S, w, 316234143225.0);
+  S = fma(S, w, -13749310575.0);
+  S = fma(S, w, 654729075.0);
+  S = fma(S, w, -34459425.0);
+  S = fma(S, w, 2027025.0);
+  S = fma(S, w, -135135.0);
+  S = fma(S, w, 10395.0);
+  S = fma(S, w, -945.0);
+  S = fma(S, w, 105.0);
+  S = fma(S, w, -15.0);
+  S = fma(S, w, 3.0);
+  S = fma(S, w, -1.0);
+  S = fma(S, w, 1.0);
+  const double M = v * aq_recip_pos(S);                       // S in (0.993, 1]
+  const double Apos = aq_log_pos(S) - (0.5 * v * v + AQ_LOG_SQRT_2PI + aq_log_pos(v));   // log Phi(-v) - log Phi(v)
+  const bool neg = x < 0.0;
+  *A = neg ? -Apos : Apos;
+  *b = M;
+  *d = neg ? -M : M;
+}
+// which: bit 0 = A wanted, bit 1 = b and d wanted (annealed sweeps take A at u and the Mills ratios at sqrt(c) u).
+// Inside the tables the polynomials, beyond them (and for NaN) aq_probit_tail: any x.
+template <int WHICH = 3, class T>
+AQ_HD void aq_probit_tab_eval(double x, const T *tab, double *A, double *b, double *d) {
+  const double v = fabs(x);
+  const double t = v * (1.0 / AQ_PT_W);
+  const bool inside = v < AQ_PT_R;            // false for NaN as well
+  const int i = (int)fmin(t, (double)(AQ_PT_NI - 1));   // (clamped: the reads stay inside the table for any x)
+  const double xl = inside ? fma(2.0, t - (double)i, -1.0) : 0.0;
+  const T *p = tab + i;
+  constexpr int S = AQ_PT_NI, F = (AQ_PT_DEG + 1) * AQ_PT_NI;
+  double pa = 0.0, pb = 0.0, pd = 0.0;
+  if (WHICH & 1) pa = p[AQ_PT_DEG * S];
+  if (WHICH & 2) { pb = p[F + AQ_PT_DEG * S]; pd = p[2 * F + AQ_PT_DEG * S]; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k = AQ_PT_DEG - 1; k >= 0; k--) {
+    if (WHICH & 1) pa = fma(pa, xl, p[k * S]);
+    if (WHICH & 2) { pb = fma(pb, xl, p[F + k * S]); pd = fma(pd, xl, p[2 * F + k * S]); }
+  }
+  const bool neg = x < 0.0;
+  double tA = 0.0, tb = 0.0, td = 0.0;
+  if (!inside) aq_probit_tail(x, &tA, &tb, &td);
+  if (WHICH & 1) *A = inside ? (neg ? -pa : pa) : tA;
+  if (WHICH & 2) { *b = inside ? pb : tb; *d = inside ? (neg ? -pd : pd) : td; }
+}
+// A, imr1, imr0 as aq_probit_A_imr returns them, from the tables where they reach and from the tail series beyond
+AQ_HD void aq_probit_A_imr_tab(double x, const double *tab, double *A, double *imr1, double *imr0) {
+  double b, d;
+  aq_probit_tab_eval<3>(x, tab, A, &b, &d);
+  const double m = 0.5 * (b + d);            // M(x)
+  *imr0 = -m;
+  *imr1 = b - m;                             // M(-x)
 }
 
 // log Phi(x) and log(1 - Phi(x)) = log Phi(-x) together.

@@ -166,6 +166,7 @@ struct aq_vb {
   int ncu = 256;
   int la_xtouch = 1;        // helper waves warm the L2 with the next phase's X operand panels (AQ_XTOUCH=0 switches it off)
   bool la_nt3_pinned = false;   // AQ_NT3 given: the annealed sweeps keep the geometry as well
+  int NT3x = -1;                // look-ahead kernel, two-tile instances: 9 residual tiles on the recurrence wave (geometry NT / NT / 9), -1 = aq_la_nt3
   int la_xhelper = 0;       // sample split of the look-ahead kernel: exchange on the helper wave (long matrix phases) or on the recurrence wave
   int chain = 0;            // > 1: chained-segment launch with that many SNP segments (aq_core_sweep_la.h, SEG)
   int *done = nullptr, *errflag = nullptr;
@@ -323,7 +324,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     a.dbg = nullptr;
     static long long *dbg_buf = nullptr;   // AQ_DIAG_DUMP=<file> with a -DAQ_DIAG_TIME build: per-role wait / total cycles of sweep 15
     const char *dump = getenv("AQ_DIAG_DUMP");
-    const size_t dbg_n = (size_t)32 * nwg * 8 * 3 + 8 * 32 * 4;   // per-wave counters of up to 32 nwg workgroups + the timeline of workgroup 0
+    const size_t dbg_n = (size_t)32 * nwg * 8 * 3 + 8 * 32 * 8;   // per-wave counters of up to 32 nwg workgroups + the timeline of workgroup 0
     if (dump && mode == 0) {
       static size_t dbg_cap = 0;
       if (dbg_n > dbg_cap) {
@@ -343,10 +344,8 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     // Annealed sweeps (c != 1): the helper wave evaluates the probit terms twice and SIMD 3 becomes the bound (42 ms against 35
     // at C3), so the recurrence wave gives three of its six residual tiles back to the matrix waves: geometry (NT, NT, 3)
     // instead of (NT, NT - 1, 6) -- the same 6 NT + 3 tiles, hence the same n_pad and residual layout in HBM (38.5 ms).
-    int NT2l = s->NT2;
-    if (s->TT == 2 && !a.c_is_one && mode == 0 && s->NT2 == s->NT - 1 && aq_la_nt3(s->NT, s->NT2, 2) == 6 && !s->la_nt3_pinned) NT2l = s->NT;
     int lrc = s->la_mask ? aq_la_launch_mask(s->NT, s->NT2, chained, grid, 0, a)
-              : s->TT == 2 ? aq_la_launch_tt2(s->NT, NT2l, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
+              : s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, s->NT3x, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
     if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
     if (chained) {
       if (s->la_mask) hipLaunchKernelGGL(aq_k_combine_segment_sums6, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
@@ -356,7 +355,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
       hipLaunchKernelGGL(aq_k_sum_parts, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->rnpart, s->sums + (size_t)4 * s->q_pad, s->laC, s->q_pad);
     if (a.dbg && s->it == 15) {
       AQ_HIP(hipDeviceSynchronize());
-      std::vector<long long> h((size_t)grid * 24 + 8 * 32 * 4);
+      std::vector<long long> h((size_t)grid * 24 + 8 * 32 * 8);
       AQ_HIP(hipMemcpy(h.data(), a.dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
       if (FILE *f = fopen(dump, "w")) {
         for (unsigned b = 0; b < grid; b++)
@@ -368,7 +367,8 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
         const long long *t = h.data() + (size_t)grid * 24;
         for (int w = 0; w < 8; w++)
           for (int i = 0; i < 32; i++)
-            fprintf(f, "%d %d %lld %lld %lld %lld\n", w, 64 + i, t[(w * 32 + i) * 4], t[(w * 32 + i) * 4 + 1], t[(w * 32 + i) * 4 + 2], t[(w * 32 + i) * 4 + 3]);
+            fprintf(f, "%d %d %lld %lld %lld %lld %lld %lld %lld\n", w, 64 + i, t[(w * 32 + i) * 8], t[(w * 32 + i) * 8 + 1], t[(w * 32 + i) * 8 + 2],
+                    t[(w * 32 + i) * 8 + 3], t[(w * 32 + i) * 8 + 4], t[(w * 32 + i) * 8 + 5], t[(w * 32 + i) * 8 + 6]);
         fclose(f);
       }
     }
@@ -555,11 +555,14 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         auto fit = [&](int tiles_needed, int nt_max, int *NTo, int *NT2o) {
           int best_tiles = 1 << 30, best_nt3 = -1;
           for (int NT = 1; NT <= nt_max; NT++)
-            for (int NT2 = NT; NT2 >= (NT > 1 ? NT - 1 : NT); NT2--) {
-              const int nt3 = aq_la_nt3(NT, NT2, s->TT), tiles = 3 * (NT + NT2) + nt3;
-              if (tiles < tiles_needed || (e3 && atoi(e3) != nt3 && s->TT == 2 && NT >= 8)) continue;
-              if (tiles < best_tiles || (tiles == best_tiles && nt3 > best_nt3)) { best_tiles = tiles; best_nt3 = nt3; *NTo = NT; *NT2o = NT2; }
-            }
+            for (int NT2 = NT; NT2 >= (NT > 1 ? NT - 1 : NT); NT2--)
+              // x9: the instance NT / NT / 9 -- measured slower at C3 than 10 / 9 / 6 (38.5 against 35.0 ms: the helper wave's fp64
+              // work crawls while the recurrence wave's MFMAs hold SIMD 3's datapath), so only on request (AQ_NT3=9)
+              for (int x9 = 0; x9 <= ((s->TT == 2 && NT >= 8 && NT2 == NT && e3 && atoi(e3) == 9) ? 1 : 0); x9++) {
+                const int nt3 = x9 ? 9 : aq_la_nt3(NT, NT2, s->TT), tiles = 3 * (NT + NT2) + nt3;
+                if (tiles < tiles_needed || (e3 && atoi(e3) != nt3 && s->TT == 2 && NT >= 8)) continue;
+                if (tiles < best_tiles || (tiles == best_tiles && nt3 > best_nt3)) { best_tiles = tiles; best_nt3 = nt3; *NTo = NT; *NT2o = NT2; s->NT3x = x9 ? 9 : -1; }
+              }
           return best_tiles;
         };
         if (pr->n <= 1056 && !getenv("AQ_LA_C")) {
@@ -1525,13 +1528,17 @@ __host__ __device__ static inline bool aq_special_one(int which, double x, doubl
     case 15: *out = aq_hs_integral(5.0, 5.0 * x, 3, 2, x2); return true;
     case 16: *out = aq_hs_integral(7.0, 7.0 * x, 4, 4, x2); return true;
     case 17: *out = aq_hs_integral(7.0, 7.0 * x, 4, 3, x2); return true;
+    // the table-driven probit terms of the sweep kernel's helper wave (aq_probit_tab.h): A, imr1, imr0
+    case 18: aq_probit_A_imr_tab(x, aq_pt_table(), &a_, &b_, &c_); *out = a_; return true;
+    case 19: aq_probit_A_imr_tab(x, aq_pt_table(), &a_, &b_, &c_); *out = b_; return true;
+    case 20: aq_probit_A_imr_tab(x, aq_pt_table(), &a_, &b_, &c_); *out = c_; return true;
     default: return false;
   }
 }
 
 extern "C" int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len) {
   if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval: bad argument");
-  if ((which == 3 || which >= 14) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
+  if ((which == 3 || (which >= 14 && which <= 17)) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
   for (int64_t i = 0; i < len; i++)
     if (!aq_special_one(which, x[i], x2 ? x2[i] : 0.0, &out[i])) return aq_fail(AQ_ERR_ARG, "aq_special_eval: unknown function id");
   return AQ_OK;
@@ -1544,8 +1551,8 @@ __global__ void aq_k_special_eval(int which, const double *x, const double *x2, 
 
 extern "C" int aq_special_eval_device(int32_t which, const double *x, const double *x2, double *out, int64_t len, int32_t device) {
   if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: bad argument");
-  if (which < 0 || which > 17) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: unknown function id");
-  if ((which == 3 || which >= 14) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: x2 required");
+  if (which < 0 || which > 20) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: unknown function id");
+  if ((which == 3 || (which >= 14 && which <= 17)) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: x2 required");
   AQ_TRY(aq_need_device(device));
   if (len == 0) return AQ_OK;
   double *dx = nullptr, *dx2 = nullptr, *dout = nullptr;

@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--no-to-tol", action="store_true",
                     help="skip the ELBO-to-tol leg (N = 1 only): the reference's default run (tol 0.1, maxit 1000, anneal (1,2,10), "
                          "thinned ELBO schedule) from loop entry to `converged`, on C2 (n=1000 p=5000 q=1000) and on the bench workload")
+    ap.add_argument("--to-tol-maxit", type=int, default=1000,
+                    help="maxit of the ELBO-to-tol leg on the bench workload (the reference's default is 1000, R/atlasqtl.R:181; C3 "
+                         "needs more sweeps than that for |dELBO| < 0.1 on an ELBO of -1.4e7: profiles/r03_elbo_to_tol_c3.json)")
     args = ap.parse_args()
 
     import torch
@@ -328,7 +331,8 @@ def main():
             out["elbo_to_tol"] = {}
             for name, (n2, p2, q2) in (("c2", (1000, 5000, 1000)), ("bench_workload", (n, p, q))):
                 X2, Y2, lh2, li2 = build_problem(n2, p2, q2, 0, q2, local_rank)
-                r2 = VbRun(Y2, X2, lh2, li2, anneal, tol=0.1, maxit=1000, thinned_elbo_eval=True, debug=True,
+                maxit2 = 1000 if name == "c2" else args.to_tol_maxit
+                r2 = VbRun(Y2, X2, lh2, li2, anneal, tol=0.1, maxit=maxit2, thinned_elbo_eval=True, debug=True,
                            device=local_rank, q_total=q2)
                 del li2
                 torch.cuda.synchronize()
@@ -338,7 +342,7 @@ def main():
                 dt2 = time.perf_counter() - t1
                 st2 = r2.status()
                 out["elbo_to_tol"][name] = {"workload": f"n={n2} p={p2} q={q2}", "seconds": dt2, "it": st2["it"],
-                                            "converged": bool(st2["converged"]), "tol": 0.1, "maxit": 1000,
+                                            "converged": bool(st2["converged"]), "tol": 0.1, "maxit": maxit2,
                                             "lb_opt": st2["lb_opt"], "sweeps_per_s": st2["it"] / dt2}
                 r2.close()
                 torch.cuda.empty_cache()

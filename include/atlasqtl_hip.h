@@ -158,6 +158,34 @@ int aq_vb_run(aq_vb_handle h);
  * Used by bench.py to time exactly K sweeps. */
 int aq_vb_run_sweeps(aq_vb_handle h, int32_t max_sweeps);
 
+/* ------------------------------------------------------------------------------------------
+ * The whole run on several GPUs of one node from ONE host process (`aq_vb_run(handle, ..., n_gpus)`), for
+ * hosts without torch.distributed -- the reference's host is R, which calls the core once, single-threaded
+ * (R/atlasqtl.R:274-278).  `prob` describes the WHOLE problem (q == q_total, host pointers; init_generate = 1 is allowed and
+ * reproduces the single-GPU draws); the library cuts the trait axis into whole 16-trait tiles (aq_vb_partition), runs one host
+ * thread and one handle per GPU and SUM-all-reduces the two small payloads of the aq_vb_advance protocol itself:
+ *   transport 0  RCCL over xGMI (librccl.so is loaded at run time; distinct devices),
+ *   transport 1  staged through host memory in fixed rank order (no RCCL; devices may repeat -- a one-GPU box can rehearse it).
+ * devices: n_gpus HIP ordinals, or NULL for 0 .. n_gpus-1.  Results are gathered into the caller's host buffers of aq_vb_multi_out
+ * (p x q column-major / q- and p-vectors; any pointer may be NULL).  Errors of any rank (e.g. AQ_ERR_NUMERIC) stop all ranks.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct aq_vb_multi_out {
+  double *beta_vb, *gam_vb, *mu_beta_vb;              /* p x q */
+  double *theta_vb, *zeta_vb, *lam2_inv_vb, *sig2_theta_vb, *tau_vb, *sig2_beta_vb;
+  int32_t *elbo_it;                                   /* ELBO trace: up to elbo_cap (iteration, value) pairs */
+  double *elbo_lb;
+  int32_t elbo_cap;
+  /* written by the call */
+  int32_t n_elbo, it, converged;
+  double lb_opt, diff_lb, sig02_inv_vb, sig2_inv_vb;
+  double seconds;                                     /* wall-clock of the run incl. set-up of the handles */
+  double core_ms;                                     /* device time of the core sweep kernel, max over the GPUs */
+} aq_vb_multi_out;
+int aq_vb_run_multi(const aq_vb_problem *prob, int32_t n_gpus, const int32_t *devices, int32_t transport, aq_vb_multi_out *out);
+/* The trait range [*k0, *k1) of part `part` of `n_parts` for q traits: whole 16-trait tiles, tile counts differing by at most
+ * one (the last part also takes the ragged end).  No GPU needed. */
+int aq_vb_partition(int32_t q, int32_t n_parts, int32_t part, int32_t *k0, int32_t *k1);
+
 typedef struct aq_vb_status {
   int32_t it;            /* sweeps done                                   */
   int32_t converged;
@@ -270,6 +298,8 @@ int aq_vb_set_state(aq_vb_handle h, const void *buf, int64_t len);
  * ratios phi/Phi, -phi/(1-Phi) (R/utils.R:172-191) from aq_probit_terms, 9 erfcx(x), x >= 0,
  * 10 / 11 / 12 log(1-Phi) - log Phi and the two Mills ratios from the pre-pass form aq_probit_A_imr.
  * 13 the short-dependency-chain sigmoid of the SNP recursion (aq_sigmoid_neg_fast).
+ * 14 - 17 compute_integral_hs_ (x = L, x2 = Q(L)); 18 / 19 / 20 log(1-Phi) - log Phi and the two Mills ratios from the piecewise
+ * polynomial tables the sweep kernel evaluates (aq_probit_tab.h; closed forms beyond |x| = 12).
  * Evaluates elementwise into out.  aq_special_eval_device runs the same switch in a kernel on `device`
  * (host pointers in and out): the device build of these functions (ocml, v_rcp_f64) is what the sweep executes.
  * ---------------------------------------------------------------------------------------- */

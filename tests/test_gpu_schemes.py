@@ -11,7 +11,7 @@ from tests.util import make_problem
 pytestmark = pytest.mark.gpu
 
 
-def _compare(ref, got, tr):
+def _compare(ref, got, tr, rtol_scale=1e-9):
     assert got["it"] == ref["it"] and got["converged"] == ref["converged"]
     lref = np.array([r["lb"] for r in tr if r["lb"] is not None])
     np.testing.assert_allclose(got["elbo_trace"][1], lref, rtol=1e-9)
@@ -20,8 +20,8 @@ def _compare(ref, got, tr):
     np.testing.assert_allclose(got["gam_vb"], ref["gam_vb"], atol=1e-9)
     np.testing.assert_allclose(got["theta_vb"], ref["theta_vb"], rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(got["zeta_vb"], ref["zeta_vb"], rtol=1e-6, atol=1e-10)
-    np.testing.assert_allclose(got["sig2_theta_vb"], ref["sig2_theta_vb"], rtol=1e-9)
-    np.testing.assert_allclose(got["sig02_inv_vb"], ref["sig02_inv_vb"], rtol=1e-9)
+    np.testing.assert_allclose(got["sig2_theta_vb"], ref["sig2_theta_vb"], rtol=rtol_scale)
+    np.testing.assert_allclose(got["sig02_inv_vb"], ref["sig02_inv_vb"], rtol=rtol_scale)
 
 
 @pytest.mark.parametrize("anneal", [None, (1, 2, 10), (3, 2, 4)])
@@ -52,7 +52,11 @@ def test_horseshoe_df_3_5_7_matches_oracle(shape, na, df):
                                         full_output=True)
     got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, None, df, 0.1, 1000, 0, prob["list_hyper"], prob["list_init"],
                                         full_output=True, debug=True)
-    _compare(ref, got, tr)
+    # df = 5, 7: lam2_inv_vb is a quotient of compute_integral_hs_ values, each a DIFFERENCE of exp(log_sum_exp(.)) of large terms
+    # (R/utils.R:446-474,516-560; tests/test_oracle.py measures the digits that loses): rounding differences of 1e-15 in the
+    # sweep come back as ~1e-9 in the scales, on either side.  The scales are held to 1e-7 there (mu_beta_vb 1e-6 and the ELBO
+    # 1e-9 as everywhere).
+    _compare(ref, got, tr, rtol_scale=1e-9 if df == 3 else 1e-7)
     np.testing.assert_allclose(got["lam2_inv_vb"], ref["lam2_inv_vb"], rtol=1e-6)
 
 

@@ -43,3 +43,20 @@ def test_short_chain_sigmoid_on_device():
     ref = np.array([float(1 / (1 + mp.exp(mp.mpf(float(v))))) for v in x])
     got = evd(13, x)
     assert np.max(np.abs(got - ref) / np.maximum(ref, 1e-300)) < 2e-15
+
+
+def test_probit_tables_on_device():
+    """Device build of the table-driven probit terms (what the helper wave of the sweep kernel evaluates, there from its LDS copy
+    of the same table) against 60-digit mpmath, tolerances as in tests/test_special.py."""
+    from tests.test_special import _probit_refs, probit_table_points, ev
+    x = probit_table_points()
+    A, imr1, imr0 = _probit_refs(x)
+    gA, g1, g0 = evd(18, x), evd(19, x), evd(20, x)
+    assert np.max(np.abs(gA - A) / np.maximum(np.abs(A), 1.0)) < 4e-15
+    scale = np.maximum(np.maximum(np.abs(imr1), np.abs(imr0)), 1.0)
+    assert np.max(np.abs(g1 - imr1) / scale) < 4e-15
+    assert np.max(np.abs(g0 - imr0) / scale) < 4e-15
+    assert np.all(g1 >= -x) and np.all(g0 <= -x)
+    for w in (18, 19, 20):                                   # host and device builds of the same header
+        h, d = ev(w, x), evd(w, x)
+        assert np.max(np.abs(h - d) / np.maximum(np.abs(h), 1.0)) < 2e-15

@@ -137,3 +137,47 @@ def test_hs_integral_matches_the_oracle_restatement():
     for which, (df, m, n) in {14: (5, 3, 3), 15: (5, 3, 2), 16: (7, 4, 4), 17: (7, 4, 3)}.items():
         ref = np.array([O.compute_integral_hs_(float(df), xi * df, m, n, qi) for xi, qi in zip(x, Q)])
         assert np.max(np.abs(ev(which, x, Q) - ref) / np.abs(ref)) < 1e-11, which
+
+
+def _probit_refs(x):
+    import mpmath as mp
+    mp.mp.dps = 60
+    phi = lambda v: mp.exp(-mp.mpf(float(v)) ** 2 / 2) / mp.sqrt(2 * mp.pi)
+    A = np.array([float(_mp_log_ndtr(-v) - _mp_log_ndtr(v)) for v in x])
+    imr1 = np.array([float(phi(v) / (mp.erfc(-mp.mpf(float(v)) / mp.sqrt(2)) / 2)) for v in x])
+    imr0 = np.array([float(-phi(v) / (mp.erfc(mp.mpf(float(v)) / mp.sqrt(2)) / 2)) for v in x])
+    return A, imr1, imr0
+
+
+def probit_table_points():
+    rng = np.random.default_rng(7)
+    edges = np.arange(0, 12.5, 0.5)                                   # interval boundaries and their neighbours
+    near = np.concatenate([edges, np.nextafter(edges, -1), np.nextafter(edges, 100)])
+    x = np.concatenate([rng.uniform(-12, 12, 6000), near, -near, np.linspace(-13, 13, 261), [0.0, -0.0, 1e-300, -1e-300, 11.999999,
+                        12.0, -12.0, 12.000001, 40.0, -40.0, 1e4]])
+    return x
+
+
+def test_probit_tables_against_mpmath():
+    """The table-driven probit terms of the sweep kernel (aq_probit_tab.h, piecewise degree-10 polynomials of A, b = imr1 - imr0
+    and d; closed forms beyond |x| = 12) against 60-digit arithmetic: A to a few ulp of max(|A|, 1), the Mills ratios to a few
+    ulp of the LARGER of the two (they enter Z = a + gam b only through b = imr1 - imr0 and a = x + imr0, R/update_vb.R:217-234),
+    and the reference's clamps (R/utils.R:180-181,188-189) hold."""
+    x = probit_table_points()
+    A, imr1, imr0 = _probit_refs(x)
+    gA, g1, g0 = ev(18, x), ev(19, x), ev(20, x)
+    assert np.max(np.abs(gA - A) / np.maximum(np.abs(A), 1.0)) < 4e-15
+    scale = np.maximum(np.maximum(np.abs(imr1), np.abs(imr0)), 1.0)
+    assert np.max(np.abs(g1 - imr1) / scale) < 4e-15
+    assert np.max(np.abs(g0 - imr0) / scale) < 4e-15
+    assert np.max(np.abs((g1 - g0) - (imr1 - imr0)) / scale) < 4e-15          # the slope b
+    # the intercept a = x + imr0 cancels for x >> 1 (a ~ -1/x): a few ulp of x is all fp64 can give, here as before
+    assert np.max(np.abs((x + g0) - (x + imr0)) / np.maximum(np.abs(x), 1.0)) < 2e-15
+    assert np.all(g1 >= -x) and np.all(g0 <= -x)
+    # continuity across the interval boundaries and at the hand-over to the closed forms
+    for e in np.arange(0.5, 12.5, 0.5):
+        lo, hi = np.nextafter(e, -1), e
+        for w in (18, 19, 20):
+            a, b = ev(w, np.array([lo, hi, -lo, -hi]))[[0, 1]], ev(w, np.array([lo, hi, -lo, -hi]))[[2, 3]]
+            assert abs(a[0] - a[1]) < 1e-13 * max(1.0, abs(a[0])) and abs(b[0] - b[1]) < 1e-13 * max(1.0, abs(b[0]))
+    assert np.all(np.isnan(ev(18, np.array([np.nan]))))

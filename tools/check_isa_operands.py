@@ -105,6 +105,7 @@ def check_kernel(name, lines, lo, hi, quiet):
     open_at_end = set()
     requests = set()
     seen = set()
+    visited = set()
     work = deque([(0, ())])
     nstates = 0
     while work:
@@ -112,6 +113,7 @@ def check_kernel(name, lines, lo, hi, quiet):
         if (b, q) in seen:
             continue
         seen.add((b, q))
+        visited.add(b)
         nstates += 1
         q = list(q)
         fall = True
@@ -146,14 +148,15 @@ def check_kernel(name, lines, lo, hi, quiet):
         if fall and b + 1 < len(blocks):
             work.append((b + 1, tuple(q)))
     tag = name.replace("_Z23aq_core_sweep_la_kernelI", "").replace("EEv10AqCoreArgs", "")
-    print(f"{tag}: {len(requests)} hand-issued requests, {len(blocks)} blocks, {nstates} (block, queue) states, "
+    unreached = len(blocks) - len(visited)
+    print(f"{tag}: {len(requests)} hand-issued requests, {len(blocks)} blocks ({unreached} unreached), {nstates} (block, queue) states, "
           f"{len(viol)} violations, {len(open_at_end)} windows open at s_endpgm")
     if not quiet or viol:
         for k in sorted(viol):
             print("    " + viol[k])
     for ln in sorted(open_at_end):
         print(f"    request of line {ln} is never covered by a wait before s_endpgm")
-    return len(viol) + len(open_at_end)
+    return len(viol) + len(open_at_end) + unreached      # a block the walk cannot reach is a block that was not checked
 
 
 def check(path, quiet):

@@ -18,7 +18,11 @@ for w in range(8):
         if len(r) == 0 or r[0, 2] == 0:
             continue
         e, c, l, a = [(x - t0) / ghz / 1e3 for x in r[0, 2:6]]
-        print(f"{w:4d} {ph:5d} {e:8.2f} {c:10.2f} {l:10.2f} {a:10.2f}   {a - l:8.2f}")
+        extra = ""
+        if r.shape[1] >= 9 and r[0, 6] > 0:     # recurrence wave: S' summed, correction applied, half of the 16 steps
+            s4, s5, s6 = [(x - t0) / ghz / 1e3 for x in r[0, 6:9]]
+            extra = f"   chain: S' ready {s4 - e:5.2f}  corrected {s5 - e:5.2f}  8 steps {s6 - e:5.2f}  16 steps {c - e:5.2f}"
+        print(f"{w:4d} {ph:5d} {e:8.2f} {c:10.2f} {l:10.2f} {a:10.2f}   {a - l:8.2f}{extra}")
 periods = []
 for w in (0, 3, 4):
     r = d[(d[:, 0] == w) & (d[:, 5] > 0)]
