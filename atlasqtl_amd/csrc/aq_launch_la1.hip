@@ -8,7 +8,22 @@ static void aq_la_go(bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &
   else hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT, NT2, false, 1>), dim3(grid), dim3(512), 0, st, a);
 }
 
-int aq_la_launch_tt1(int NT, int NT2, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a) {
+template <int NT, int NT2, int N3>
+static void aq_la_go3(bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a) {
+  if (seg) hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT, NT2, true, 1, false, N3>), dim3(grid), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((aq_core_sweep_la_kernel<NT, NT2, false, 1, false, N3>), dim3(grid), dim3(512), 0, st, a);
+}
+
+int aq_la_launch_tt1(int NT, int NT2, int nt3x, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a) {
+  if (nt3x > 0) {
+#define AQ_L3(NT_)                                                                                                  \
+    if (NT == NT_ && nt3x == 3 && NT2 == NT_) { aq_la_go3<NT_, NT_, 3>(seg, grid, st, a); return 0; }               \
+    if (NT == NT_ && nt3x == 6 && NT2 == NT_ - 1) { aq_la_go3<NT_, NT_ - 1, 6>(seg, grid, st, a); return 0; }       \
+    if (NT == NT_ && nt3x == 9 && NT2 == NT_) { aq_la_go3<NT_, NT_, 9>(seg, grid, st, a); return 0; }
+    AQ_L3(8) AQ_L3(9) AQ_L3(10) AQ_L3(11)
+#undef AQ_L3
+    return -1;
+  }
 #define AQ_LA(NT_)                                                                        \
   if (NT == NT_ && NT2 == NT_) { aq_la_go<NT_, NT_>(seg, grid, st, a); return 0; }        \
   if (NT == NT_ && NT2 == NT_ - 1 && NT_ > 1) { aq_la_go<NT_, (NT_ > 1 ? NT_ - 1 : 1)>(seg, grid, st, a); return 0; }

@@ -10,6 +10,7 @@
 // All of it is HBM-bound streaming: one read of X for the column statistics, one read + one write for the standardised
 // matrix with its column hashes, one gather pass for the compaction.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <algorithm>
 #include <cmath>
@@ -193,6 +194,10 @@ static int aq_prepare_x(aq_prep *h, const T *X_host) {
     AQR_HIP(hipMemcpy(h->mean.data(), dmean, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
     AQR_HIP(hipMemcpy(h->sd.data(), dsd, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
     AQR_HIP(hipMemcpy(hash.data(), dhash, hash.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (const char *e = getenv("AQ_PREP_HASH_MASK")) {   // test hook: truncate the hashes so that different columns collide
+      const unsigned long long mask = strtoull(e, nullptr, 0);
+      for (auto &v : hash) v &= mask;
+    }
     // duplicated(mat, MARGIN = 2) among the non-constant columns: the first column of each hash class is kept; a later
     // member is removed once a bitwise comparison on the device has confirmed it (a 128-bit collision is not ruled out)
     struct Key { unsigned long long a, b; bool operator==(const Key &o) const { return a == o.a && b == o.b; } };
@@ -216,9 +221,33 @@ static int aq_prepare_x(aq_prep *h, const T *X_host) {
       AQR_HIP(hipMemset(dout, 0, out.size() * sizeof(int)));
       hipLaunchKernelGGL((aq_k_cols_equal<T>), dim3((unsigned)cand.size()), dim3(256), 0, 0, dX, n, dmean, dsd, dpairs, dout);
       AQR_HIP(hipMemcpy(out.data(), dout, out.size() * sizeof(int), hipMemcpyDeviceToHost));
-      for (size_t c = 0; c < cand.size(); c++)
-        if (out[c] == 0) { h->bool_coll[cand[c]] = 1; h->dup_of[cand[c]] = pairs[2 * c]; }
-      // (a confirmed-different column with a colliding hash simply stays: it is not a duplicate)
+      // A candidate the bitwise comparison found DIFFERENT from the first column of its hash class (a 128-bit collision) is a
+      // column of its own: it joins the class, and every later candidate of the class that differs from the first member is
+      // compared with the further members as well, in column order (one pair per launch: this never happens in practice).
+      auto equal_on_device = [&](int ca, int cb, bool *eq) -> int {
+        const int pr2[2] = {ca, cb};
+        int res = 0;
+        if (hipMemcpy(dpairs, pr2, sizeof(pr2), hipMemcpyHostToDevice) != hipSuccess || hipMemset(dout, 0, sizeof(int)) != hipSuccess)
+          return aq_fail_ext(AQ_ERR_DEVICE, "aq_prepare_data: duplicate check failed");
+        hipLaunchKernelGGL((aq_k_cols_equal<T>), dim3(1), dim3(256), 0, 0, dX, n, dmean, dsd, dpairs, dout);
+        if (hipMemcpy(&res, dout, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+          return aq_fail_ext(AQ_ERR_DEVICE, "aq_prepare_data: duplicate check failed");
+        *eq = (res == 0);
+        return AQ_OK;
+      };
+      for (size_t c = 0; c < cand.size(); c++) {
+        const int j = cand[c];
+        if (out[c] == 0) { h->bool_coll[j] = 1; h->dup_of[j] = pairs[2 * c]; continue; }
+        std::vector<int> &members = seen[Key{hash[2 * (size_t)j], hash[2 * (size_t)j + 1]}];
+        bool dup = false;
+        for (size_t m = 1; m < members.size() && !dup; m++) {
+          bool eq = false;
+          rc = equal_on_device(members[m], j, &eq);
+          if (rc != AQ_OK) goto done;
+          if (eq) { h->bool_coll[j] = 1; h->dup_of[j] = members[m]; dup = true; }
+        }
+        if (!dup) members.push_back(j);
+      }
     }
     int kept = 0;
     for (int j = 0; j < p; j++)

@@ -345,7 +345,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     // at C3), so the recurrence wave gives three of its six residual tiles back to the matrix waves: geometry (NT, NT, 3)
     // instead of (NT, NT - 1, 6) -- the same 6 NT + 3 tiles, hence the same n_pad and residual layout in HBM (38.5 ms).
     int lrc = s->la_mask ? aq_la_launch_mask(s->NT, s->NT2, chained, grid, 0, a)
-              : s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, s->NT3x, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, chained, grid, 0, a);
+              : s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, s->NT3x, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, s->NT3x, chained, grid, 0, a);
     if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
     if (chained) {
       if (s->la_mask) hipLaunchKernelGGL(aq_k_combine_segment_sums6, dim3((s->q_pad + 255) / 256), dim3(256), 0, 0, s->sums, s->q_pad, s->chain);
@@ -489,7 +489,10 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       const size_t gk_b = ntile_ * nb_ * AQ_GK_STRIDE * sizeof(double);
       const size_t rest_b = 2 * ntile_ * nb_ * 256 * sizeof(double) + 3 * (size_t)(pr->n + 64) * nb_ * 16 * sizeof(double) * 2 +
                             3 * ntile_ * (size_t)(pr->n + 64) * 16 * sizeof(double);
-      if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess || (double)(gk_b + rest_b) * 1.05 > (double)free_b) la_mask_ok = false;
+      // decided on the device's TOTAL memory (minus a tenth), not on what happens to be free: the same problem gets the same
+      // kernel on every rank and in every run, so a checkpoint of one is accepted by the other.  Should the allocation then fail
+      // because other processes hold memory, aq_vb_create reports the out-of-memory error (AQ_GK_MAX_GB lowers the limit).
+      if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess || (double)(gk_b + rest_b) * 1.05 > 0.9 * (double)tot_b) la_mask_ok = false;
       if (const char *e = getenv("AQ_GK_MAX_GB")) if ((double)gk_b > atof(e) * 1e9) la_mask_ok = false;   // test hook: force the fallback
     }
     const bool la_split_ok = !has_missing && pr->n > 1056 && n_la_ok && !(ek && atoi(ek) >= 2);   // complete Y, large n
@@ -552,22 +555,40 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         // smallest geometry that holds ntiles: NT in 1..11, NT2 in {NT, NT - 1}, plus the recurrence wave's aq_la_nt3 tiles;
         // among equals the one with more tiles on the recurrence wave (AQ_NT3=0/3/6 pins its tile count for experiments)
         const char *e3 = getenv("AQ_NT3");
-        auto fit = [&](int tiles_needed, int nt_max, int *NTo, int *NT2o) {
+        auto fit = [&](int tiles_needed, int nt_max, int *NTo, int *NT2o, int *N3xo) {
           int best_tiles = 1 << 30, best_nt3 = -1;
           for (int NT = 1; NT <= nt_max; NT++)
             for (int NT2 = NT; NT2 >= (NT > 1 ? NT - 1 : NT); NT2--)
               // x9: the instance NT / NT / 9 -- measured slower at C3 than 10 / 9 / 6 (38.5 against 35.0 ms: the helper wave's fp64
               // work crawls while the recurrence wave's MFMAs hold SIMD 3's datapath), so only on request (AQ_NT3=9)
               for (int x9 = 0; x9 <= ((s->TT == 2 && NT >= 8 && NT2 == NT && e3 && atoi(e3) == 9) ? 1 : 0); x9++) {
-                const int nt3 = x9 ? 9 : aq_la_nt3(NT, NT2, s->TT), tiles = 3 * (NT + NT2) + nt3;
+                int nt3 = x9 ? 9 : aq_la_nt3(NT, NT2, s->TT);
+                // one tile per workgroup, unsplit (the trait shards of N = 2, 4: MFMA-bound on three SIMDs while SIMD 3 only runs
+                // the chain): three residual tiles on the recurrence wave by default -- q = 5000: 19.55 -> 18.78 ms, q = 2500:
+                // 15.48 -> 14.83; six or nine make its chain + tiles the bound (30 and 33 ms).  AQ_NT3 = 0 / 3 / 6 / 9 pins the count.
+                int x1 = -1;
+                bool second = false;
+                if (s->TT == 1 && !s->la_mask && NT >= 8 && nt_max <= 11) {
+                  const int w = e3 ? atoi(e3) : 3;
+                  if ((w == 3 || w == 9) && NT2 == NT) x1 = w;
+                  else if (w == 6 && NT2 == NT - 1) x1 = w;
+                  else if (e3 && w != 0) continue;
+                  if (x1 > 0) nt3 = x1;
+                  second = !e3 && x1 > 0;        // by default the plain geometry competes as well (it wins when it needs fewer tiles)
+                }
+                if (second) {
+                  const int tiles0 = 3 * (NT + NT2);
+                  if (tiles0 >= tiles_needed && tiles0 < best_tiles) { best_tiles = tiles0; best_nt3 = 0; *NTo = NT; *NT2o = NT2; *N3xo = -1; }
+                }
+                const int tiles = 3 * (NT + NT2) + nt3;
                 if (tiles < tiles_needed || (e3 && atoi(e3) != nt3 && s->TT == 2 && NT >= 8)) continue;
-                if (tiles < best_tiles || (tiles == best_tiles && nt3 > best_nt3)) { best_tiles = tiles; best_nt3 = nt3; *NTo = NT; *NT2o = NT2; s->NT3x = x9 ? 9 : -1; }
+                if (tiles < best_tiles || (tiles == best_tiles && nt3 > best_nt3)) { best_tiles = tiles; best_nt3 = nt3; *NTo = NT; *NT2o = NT2; *N3xo = x9 ? 9 : x1; }
               }
           return best_tiles;
         };
         if (pr->n <= 1056 && !getenv("AQ_LA_C")) {
           s->laC = 1;
-          const int tiles = fit(ntiles, 11, &s->NT, &s->NT2);    // n <= 1056 always fits (11, 11) ...
+          const int tiles = fit(ntiles, 11, &s->NT, &s->NT2, &s->NT3x);    // n <= 1056 always fits (11, 11) ...
           if (tiles >= (1 << 30)) { delete s; return aq_fail(AQ_ERR_ARG, "AQ_NT3 excludes every look-ahead geometry for this n"); }   // ... unless the test hook forbids it
           s->n_pad = 16 * tiles;
           // Few trait groups (a trait shard of a multi-GPU run, a small q): the CUs left idle share the samples.  Per SNP block an
@@ -579,11 +600,11 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
           if (s->TT == 1 && !s->la_mask && !getenv("AQ_LA_NOSPLIT")) {
             double best = std::max(0.213 * (s->NT + s->NT2) + 1.0, 3.3) * 0.95;   // a split must win by 5 %
             for (int C = 2; C <= 8 && (long long)s->ntile * C <= s->ncu; C++) {
-              int NT = 0, NT2 = 0;
-              const int tiles_c = fit((ntiles + C - 1) / C, 18, &NT, &NT2);
+              int NT = 0, NT2 = 0, N3x = -1;
+              const int tiles_c = fit((ntiles + C - 1) / C, 18, &NT, &NT2, &N3x);
               if (tiles_c >= (1 << 30)) continue;
               const double cost = std::max(0.213 * (NT + NT2) + 1.0, 4.5 + 0.2 * (C - 2));
-              if (cost < best - 1e-9) { best = cost; s->laC = C; s->NT = NT; s->NT2 = NT2; s->n_pad = 16 * tiles_c * C; }
+              if (cost < best - 1e-9) { best = cost; s->laC = C; s->NT = NT; s->NT2 = NT2; s->NT3x = N3x; s->n_pad = 16 * tiles_c * C; }
             }
           }
         } else {
@@ -595,12 +616,12 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
           const char *ec = getenv("AQ_LA_C");
           for (int C = 2; C <= 8; C++) {
             if (ec && atoi(ec) != C) continue;
-            int NT = 0, NT2 = 0;
-            const int tiles = fit((ntiles + C - 1) / C, 18, &NT, &NT2);
+            int NT = 0, NT2 = 0, N3x = -1;
+            const int tiles = fit((ntiles + C - 1) / C, 18, &NT, &NT2, &N3x);
             if (tiles >= (1 << 30)) continue;
             const double rounds = (double)(((long long)s->ntile * C + s->ncu - 1) / s->ncu);
             const double cost = rounds * std::max(0.213 * (NT + NT2) + 1.0, 4.5 + 0.2 * (C - 2));
-            if (cost < best - 1e-9) { best = cost; s->laC = C; s->NT = NT; s->NT2 = NT2; s->n_pad = 16 * tiles * C; }
+            if (cost < best - 1e-9) { best = cost; s->laC = C; s->NT = NT; s->NT2 = NT2; s->NT3x = N3x; s->n_pad = 16 * tiles * C; }
           }
           if (best >= 1e300) { delete s; return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead geometry for this n"); }
           // Who exchanges the partial S': the recurrence wave at the start of its chain.  The helper wave can do it a block ahead
@@ -1273,9 +1294,16 @@ extern "C" int aq_vb_set_state(aq_vb_handle s, const void *buf, int64_t len) {
   const char *o = (const char *)buf;
   std::memcpy(&h, o, sizeof(h)); o += sizeof(h);
   if (h.magic != AQ_STATE_MAGIC) return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: not an atlasqtl-hip state blob");
-  if (h.n != s->n || h.p != s->p || h.q != s->q || h.q_total != s->q_total || h.p_pad != s->p_pad || h.q_pad != s->q_pad ||
-      h.n_pad != s->n_pad || h.core_kernel != aq_core_kernel_id(s) || h.has_missing != (int)s->has_missing)
-    return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state was saved for a different problem shape or kernel geometry");
+  if (h.n != s->n || h.p != s->p || h.q != s->q || h.q_total != s->q_total || h.has_missing != (int)s->has_missing)
+    return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state was saved for a different problem shape");
+  if (h.core_kernel != aq_core_kernel_id(s))
+    return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state was saved by core kernel " + std::to_string(h.core_kernel) + ", this handle runs kernel " +
+                                   std::to_string(aq_core_kernel_id(s)) + " (0 look-ahead MFMA, 2 generic, 3 masked two-barrier): create the handle with AQ_KERNEL / "
+                                   "AQ_GK_MAX_GB set as for the run that saved it");
+  if (h.p_pad != s->p_pad || h.q_pad != s->q_pad || h.n_pad != s->n_pad)
+    return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: same problem, different kernel geometry (padding " + std::to_string(h.n_pad) + " / " + std::to_string(h.q_pad) +
+                                   " saved, " + std::to_string(s->n_pad) + " / " + std::to_string(s->q_pad) + " here): the launch plan depends on the "
+                                   "device's CU count and on AQ_TT / AQ_LA_C / AQ_NT3; resume with the settings of the run that saved the state");
   if (h.trait_offset != s->trait_offset)
     return aq_fail(AQ_ERR_ARG, "aq_vb_set_state: the state belongs to another trait shard (trait_offset differs)");
   if (h.scheme_df != s->scheme + 16 * s->df)

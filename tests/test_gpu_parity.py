@@ -156,6 +156,24 @@ def test_bench_kernel_instance_matches_oracle(shape, chain, tt, stagger, monkeyp
     _check_state(ref, got)
 
 
+@pytest.mark.parametrize("tt,nt3", [(1, 3), (1, 6), (1, 9), (2, 9), (2, 3)])
+@pytest.mark.parametrize("chain", [0, 3])
+def test_recurrence_wave_tile_counts_match_oracle(tt, nt3, chain, monkeypatch):
+    """The instances in which the recurrence wave owns 3 / 6 / 9 residual tiles (geometries NT/NT/3, NT/NT-1/6, NT/NT/9 of the
+    same 63 tiles at n = 1000), for one and two trait tiles per workgroup -- with one tile the next block's cross-block
+    correction is accumulated inside the chain, with two the helper wave forms it -- plain and chained: whole annealed run."""
+    monkeypatch.setenv("AQ_TT", str(tt))
+    monkeypatch.setenv("AQ_NT3", str(nt3))
+    monkeypatch.setenv("AQ_CHAIN", str(chain))
+    monkeypatch.setenv("AQ_LA_NOSPLIT", "1")
+    prob = make_problem(1000, 150, 40, p_act=8, prob_assoc=0.3)
+    ref, got, tr = _run_both(prob, (1, 2, 10), 1000)
+    assert got["core_kernel"] == 0 and got["it"] == ref["it"] and got["converged"] == ref["converged"]
+    lref = np.array([r["lb"] for r in tr if r["lb"] is not None])
+    np.testing.assert_allclose(got["elbo_trace"][1], lref, rtol=1e-9)
+    _check_state(ref, got)
+
+
 @pytest.mark.parametrize("tt", [1, 2])
 @pytest.mark.parametrize("n", [20, 100, 200, 330, 512, 600, 768, 860, 1024, 1040])
 def test_look_ahead_kernel_every_tile_count_matches_oracle(n, tt, monkeypatch):

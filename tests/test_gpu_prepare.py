@@ -84,3 +84,27 @@ def test_prepared_data_feeds_the_run_without_a_host_copy_of_x():
     b = A.atlasqtl(Y=d["Y"], X=d["X"].astype(float), p0=(3, 9), user_seed=4, verbose=0, full_output=True)
     assert a.converged and a.it == b.it and a.lb_opt == b.lb_opt
     np.testing.assert_array_equal(a.gam_vb, b.gam_vb)
+
+
+@pytest.mark.parametrize("mask", ["0", "0x3"])
+def test_duplicates_found_behind_hash_collisions(mask, monkeypatch):
+    """rm_collinear_ = duplicated(mat, MARGIN = 2) (R/utils.R:304-343) keeps the first of every group of identical columns.  The
+    device finds candidates by a 128-bit column hash and confirms them bitwise; with the hashes truncated (test hook) DIFFERENT
+    columns share a hash class, and a duplicate of a column that is not the first of its class must still be found."""
+    from atlasqtl_amd.prepare import prepare_on_device
+    from oracle import prepare_oracle as PO
+    monkeypatch.setenv("AQ_PREP_HASH_MASK", mask)
+    rng = np.random.default_rng(5)
+    n = 60
+    base = rng.binomial(2, 0.3, size=(n, 7)).astype(np.float64)
+    #            0        1        2        3 = dup of 1   4 = dup of 2   5        6 = dup of 0   7 = dup of 5   8 = dup of 1
+    X = np.column_stack([base[:, 0], base[:, 1], base[:, 2], base[:, 1], base[:, 2], base[:, 3], base[:, 0], base[:, 3], base[:, 1]])
+    Y = rng.normal(size=(n, 3))
+    prep, cst, coll, dup_of = prepare_on_device(Y, X, 0)
+    try:
+        _, _, cst_o, coll_o = PO.prepare_xy(Y, X)
+        assert not cst.any() and not cst_o.any()
+        assert list(np.where(coll)[0]) == [3, 4, 6, 7, 8] == list(np.where(coll_o)[0])
+        assert list(dup_of[[3, 4, 6, 7, 8]]) == [1, 2, 0, 5, 1]
+    finally:
+        prep.close()
