@@ -81,6 +81,7 @@ SYMBOLS = {
     "aq_vb_run": (C.c_int, [C.c_void_p]),
     "aq_vb_run_sweeps": (C.c_int, [C.c_void_p, C.c_int32]),
     "aq_vb_get_status": (C.c_int, [C.c_void_p, C.POINTER(AqVbStatus)]),
+    "aq_vb_get_overrides": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int32]),
     "aq_vb_get_elbo_trace": (C.c_int32, [C.c_void_p, ip, dp, C.c_int32]),
     "aq_vb_get_result": (C.c_int, [C.c_void_p, dp, dp, dp, dp, dp, dp, dp, dp, dp]),
     "aq_vb_run_multi": (C.c_int, [C.POINTER(AqVbProblem), C.c_int32, ip, C.c_int32, C.POINTER(AqVbMultiOut)]),

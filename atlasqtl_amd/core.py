@@ -381,7 +381,11 @@ class VbRun:
     def status(self):
         st = AqVbStatus()
         check(lib().aq_vb_get_status(self.h, C.byref(st)), "aq_vb_get_status")
-        return {f[0]: getattr(st, f[0]) for f in AqVbStatus._fields_}
+        out = {f[0]: getattr(st, f[0]) for f in AqVbStatus._fields_}
+        buf = C.create_string_buffer(1024)
+        lib().aq_vb_get_overrides(self.h, buf, 1024)
+        out["overrides"] = buf.value.decode()          # AQ_* environment hooks in effect ("" = the library's own launch plan)
+        return out
 
     def elbo_trace(self):
         cap = 4096

@@ -367,6 +367,10 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     constexpr bool DEEP = (TT == 1) && (NTC >= 4);
 #endif
     constexpr int DB = !DEEP ? 1 : AQ_FORCE_DEEP_DB;
+#elif defined(AQ_FORCE_DEEP_MASK_DB)   // libatlasqtl_hip_deepmask.so (make deepmask): round 2's faulting configuration -- the deep scheme in
+    // EVERY MASK instance, AQ_FORCE_DEEP_MASK_DB buffers -- as a library of its own, for the one GPU run of tests/test_gpu_sharded.py under it
+    constexpr bool DEEP = (TT == 1) && (NTC >= 4) && (MASK || true);
+    constexpr int DB = !DEEP ? 1 : MASK ? AQ_FORCE_DEEP_MASK_DB : (NT <= 11) ? AQ_DEEP_TT1 : 3;
 #else
     constexpr bool DEEP = (TT == 1) && (NTC >= 4) && (!MASK || (SEG && NT <= 11));
     constexpr int DB = !DEEP ? 1 : (!MASK && NT <= 11) ? AQ_DEEP_TT1 : 3;
@@ -880,6 +884,11 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
     //   A = log(1-Phi(u)) - log Phi(u)      src/coreLoop.cpp:75-76 (its log_Phi / log_1_min_Phi inputs, R/...core.R:293-295)
     //   Z = a + gam b,  a = u + imr0/sqrt(c), b = (imr1 - imr0)/sqrt(c) at U = sqrt(c) u       R/update_vb.R:217-234
     // This wave shares its SIMD only with the recurrence wave, whose dependent chain leaves the VALU mostly idle.
+    // Instruction priority: at equal priority this wave's fp64 operations alternate with the recurrence wave's 64-cycle MFMAs --
+    // one VALU operation per MFMA slot, a crawl; raised, its bursts run at the VALU's own rate and the MFMAs fill the gaps.
+    if (a.hprio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (a.hprio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.hprio == 1) __builtin_amdgcn_s_setprio(1);
     const size_t tbase = (size_t)(tile0 + (ht >> 4)) * a.p_pad * 16 + (ht & 15);   // this lane's tile and column
     const double zk = a.zeta[ktrait];
     typedef __attribute__((address_space(3))) const double aq_lds_cdouble;

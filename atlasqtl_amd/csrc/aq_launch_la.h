@@ -13,4 +13,5 @@ int aq_la_launch_tt1(int NT, int NT2, int nt3x, bool seg, unsigned grid, hipStre
 // nt3x = 9: the instance with nine residual tiles on the recurrence wave (NT2 == NT, NT in 8..11); -1: aq_la_nt3's count
 int aq_la_launch_tt2(int NT, int NT2, int nt3x, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a);
 // the MASK instances (Y with missing values; one trait tile per workgroup): aq_launch_la1m.hip
-int aq_la_launch_mask(int NT, int NT2, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a);
+// nt3x = 3: three residual tiles on the recurrence wave (NT2 == NT, NT in 8..11); -1: none
+int aq_la_launch_mask(int NT, int NT2, int nt3x, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a);

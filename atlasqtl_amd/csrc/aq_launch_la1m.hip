@@ -3,7 +3,8 @@
 #include "aq_launch_la.h"
 #include "aq_core_sweep_la.h"
 
-int aq_la_launch_mask(int NT, int NT2, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a) {
+int aq_la_launch_mask(int NT, int NT2, int nt3x, bool seg, unsigned grid, hipStream_t st, const AqCoreArgs &a) {
+  if (nt3x > 0) return -1;   // residual tiles on the recurrence wave of a MASK instance: tried (NT / NT / 3, chained), hung on the GPU; not built
 #define AQ_LA(NT_)                                                                                                                 \
   if (NT == NT_ && (NT2 == NT_ || (NT2 == NT_ - 1 && NT_ > 1))) {                                                                  \
     if (NT2 == NT_) {                                                                                                              \

@@ -167,6 +167,7 @@ struct aq_vb {
   int la_xtouch = 1;        // helper waves warm the L2 with the next phase's X operand panels (AQ_XTOUCH=0 switches it off)
   bool la_nt3_pinned = false;   // AQ_NT3 given: the annealed sweeps keep the geometry as well
   int NT3x = -1;                // look-ahead kernel, two-tile instances: 9 residual tiles on the recurrence wave (geometry NT / NT / 9), -1 = aq_la_nt3
+  int la_hprio = 0;         // s_setprio level of the helper wave (AQ_HPRIO)
   int la_xhelper = 0;       // sample split of the look-ahead kernel: exchange on the helper wave (long matrix phases) or on the recurrence wave
   int chain = 0;            // > 1: chained-segment launch with that many SNP segments (aq_core_sweep_la.h, SEG)
   int *done = nullptr, *errflag = nullptr;
@@ -199,7 +200,20 @@ struct aq_vb {
   std::string fail_msg;
   bool errflag_forced = false;   // test hook aq_vb_debug_raise_errflag
   int budget = -1;
+  std::string overrides;   // "NAME=value ..." of the AQ_* environment hooks that were set when the handle was created
 };
+
+// Environment overrides of the launch plan (test and experiment hooks: AQ_TT, AQ_CHAIN, AQ_LA_C, ...).  Every one that is SET when a
+// handle is created is recorded in the handle and reported by aq_vb_get_overrides, so that a host which inherits such a variable
+// from its environment -- an R session, a batch script -- can see that the plan is not the library's own.
+static const char *aq_env(aq_vb *s, const char *name) {
+  const char *v = getenv(name);
+  if (v && s) {
+    const std::string item = std::string(name) + "=" + v;
+    if (s->overrides.find(item) == std::string::npos) s->overrides += (s->overrides.empty() ? "" : " ") + item;
+  }
+  return v;
+}
 
 static void aq_free_all(aq_vb *s) {
   if (!s) return;
@@ -316,6 +330,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     a.done = s->done; a.errflag = s->errflag; a.stagger = s->stagger;
     a.C = s->laC; a.xhelper = s->la_xhelper; a.Pbuf = s->Pbuf; a.pflag = s->pflag; a.rnpart = s->rnpart;
     a.xtouch = s->la_xtouch;
+    a.hprio = s->la_hprio;
     a.mis = s->mis; a.GK = s->GK; a.tau = s->tau; a.log_tau = s->log_tau;
     a.sig2_inv_p = &s->sc->sig2_inv; a.log_sig2_inv_p = &s->sc->log_sig2_inv;
     if (s->laC > 1 && (!a.Pbuf || !a.rnpart || !a.errflag)) return aq_fail(AQ_ERR_DEVICE, "sample split without its exchange buffers");
@@ -344,7 +359,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     // Annealed sweeps (c != 1): the helper wave evaluates the probit terms twice and SIMD 3 becomes the bound (42 ms against 35
     // at C3), so the recurrence wave gives three of its six residual tiles back to the matrix waves: geometry (NT, NT, 3)
     // instead of (NT, NT - 1, 6) -- the same 6 NT + 3 tiles, hence the same n_pad and residual layout in HBM (38.5 ms).
-    int lrc = s->la_mask ? aq_la_launch_mask(s->NT, s->NT2, chained, grid, 0, a)
+    int lrc = s->la_mask ? aq_la_launch_mask(s->NT, s->NT2, s->NT3x, chained, grid, 0, a)
               : s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, s->NT3x, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, s->NT3x, chained, grid, 0, a);
     if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
     if (chained) {
@@ -461,11 +476,11 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, pr->device) == hipSuccess && prop.multiProcessorCount > 0) s->ncu = prop.multiProcessorCount;
-    if (const char *e = getenv("AQ_NCU")) s->ncu = atoi(e) > 0 ? atoi(e) : s->ncu;
+    if (const char *e = aq_env(s, "AQ_NCU")) s->ncu = atoi(e) > 0 ? atoi(e) : s->ncu;
   }
   {
     // default: look-ahead kernel (complete Y, n <= 1056); AQ_KERNEL=2 forces the generic wave-per-trait kernel
-    const char *ek = getenv("AQ_KERNEL");
+    const char *ek = aq_env(s, "AQ_KERNEL");
     // missing values: masked blocked MFMA kernel while n fits 8 waves x 16 residual tiles and no trait misses more
     // than AQ_MIS_MMAX samples; otherwise (and with AQ_KERNEL=2) the generic kernel
     int max_missing = 0;
@@ -493,7 +508,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       // kernel on every rank and in every run, so a checkpoint of one is accepted by the other.  Should the allocation then fail
       // because other processes hold memory, aq_vb_create reports the out-of-memory error (AQ_GK_MAX_GB lowers the limit).
       if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess || (double)(gk_b + rest_b) * 1.05 > 0.9 * (double)tot_b) la_mask_ok = false;
-      if (const char *e = getenv("AQ_GK_MAX_GB")) if ((double)gk_b > atof(e) * 1e9) la_mask_ok = false;   // test hook: force the fallback
+      if (const char *e = aq_env(s, "AQ_GK_MAX_GB")) if ((double)gk_b > atof(e) * 1e9) la_mask_ok = false;   // test hook: force the fallback
     }
     const bool la_split_ok = !has_missing && pr->n > 1056 && n_la_ok && !(ek && atoi(ek) >= 2);   // complete Y, large n
     if (!la_mask_ok && (has_missing || (pr->n > 1056 && !la_split_ok)) && pr->n <= 16384 && max_missing <= AQ_MIS_MMAX && !(ek && atoi(ek) == 2)) {
@@ -512,7 +527,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
             if (cost < best - 1e-9) { best = cost; s->misC = C; s->NT = NT; }
           }
       }
-      if (const char *e = getenv("AQ_MIS_C")) {   // test hook: force the sample split at small n
+      if (const char *e = aq_env(s, "AQ_MIS_C")) {   // test hook: force the sample split at small n
         int C = atoi(e);
         if (C >= 1 && C <= 8) {
           s->misC = C;
@@ -526,7 +541,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       // generic kernel geometry: n_pad = 64 * NE * WPT samples, WPT waves (and workgroups) per trait (tile)
       s->use_tw = true;
       s->WPT = pr->n <= 2048 ? 1 : pr->n <= 5120 ? 2 : 4;
-      if (const char *e = getenv("AQ_TW_WPT")) { int v = atoi(e); if ((v == 2 || v == 4) && v > s->WPT) s->WPT = v; }   // test hook
+      if (const char *e = aq_env(s, "AQ_TW_WPT")) { int v = atoi(e); if ((v == 2 || v == 4) && v > s->WPT) s->WPT = v; }   // test hook
       const int per_lane = (pr->n + 64 * s->WPT - 1) / (64 * s->WPT);
       s->NE = per_lane <= 4 ? 4 : per_lane <= 8 ? 8 : per_lane <= 16 ? 16 : per_lane <= 32 ? 32 : 40;
     }
@@ -543,7 +558,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       // (Crossover measured at n = 1000, 256 CUs: 448 tiles -- one round of two-tile workgroups, 27.4 ms, against 1.75 rounds of
       // one-tile workgroups; q = 8000: 27.5 vs 31.1 ms, q = 6144: 27.5 vs 23.4.)
       s->TT = (4LL * s->ntile >= 7LL * s->ncu) ? 2 : 1;
-      if (const char *e = getenv("AQ_TT")) s->TT = atoi(e) == 2 ? 2 : 1;
+      if (const char *e = aq_env(s, "AQ_TT")) s->TT = atoi(e) == 2 ? 2 : 1;
       if (s->la_mask) s->TT = 1;   // 16 per-trait Gram blocks per trait tile in LDS: one tile per workgroup
       if (s->TT == 2) {
         s->q_pad = (pr->q + 31) / 32 * 32;
@@ -554,7 +569,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       {
         // smallest geometry that holds ntiles: NT in 1..11, NT2 in {NT, NT - 1}, plus the recurrence wave's aq_la_nt3 tiles;
         // among equals the one with more tiles on the recurrence wave (AQ_NT3=0/3/6 pins its tile count for experiments)
-        const char *e3 = getenv("AQ_NT3");
+        const char *e3 = aq_env(s, "AQ_NT3");
         auto fit = [&](int tiles_needed, int nt_max, int *NTo, int *NT2o, int *N3xo) {
           int best_tiles = 1 << 30, best_nt3 = -1;
           for (int NT = 1; NT <= nt_max; NT++)
@@ -586,7 +601,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
               }
           return best_tiles;
         };
-        if (pr->n <= 1056 && !getenv("AQ_LA_C")) {
+        if (pr->n <= 1056 && !aq_env(s, "AQ_LA_C")) {
           s->laC = 1;
           const int tiles = fit(ntiles, 11, &s->NT, &s->NT2, &s->NT3x);    // n <= 1056 always fits (11, 11) ...
           if (tiles >= (1 << 30)) { delete s; return aq_fail(AQ_ERR_ARG, "AQ_NT3 excludes every look-ahead geometry for this n"); }   // ... unless the test hook forbids it
@@ -597,7 +612,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
           // (4.5 us with two parts, measured at n = 1000: 4.53; + 0.2 per further part).  All parts must run at once.
           // (Not with missing values: there the chain is longer and the helper wave loaded -- q = 1250 with 5 % NA: 19.3 ms unsplit,
           // 20.1 split.  AQ_LA_NOSPLIT=1 keeps one workgroup per group: experiments.)
-          if (s->TT == 1 && !s->la_mask && !getenv("AQ_LA_NOSPLIT")) {
+          if (s->TT == 1 && !s->la_mask && !aq_env(s, "AQ_LA_NOSPLIT")) {
             double best = std::max(0.213 * (s->NT + s->NT2) + 1.0, 3.3) * 0.95;   // a split must win by 5 %
             for (int C = 2; C <= 8 && (long long)s->ntile * C <= s->ncu; C++) {
               int NT = 0, NT2 = 0, N3x = -1;
@@ -613,7 +628,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
           // exchange + chain (4.5 us with two parts, + 0.2 per further part), whichever is longer.  (AQ_LA_C forces the split at small n: test hook.)
           s->TT = 1; s->q_pad = (pr->q + 15) / 16 * 16; s->ntile = s->q_pad / 16; s->stagger = 0;
           double best = 1e300;
-          const char *ec = getenv("AQ_LA_C");
+          const char *ec = aq_env(s, "AQ_LA_C");
           for (int C = 2; C <= 8; C++) {
             if (ec && atoi(ec) != C) continue;
             int NT = 0, NT2 = 0, N3x = -1;
@@ -629,12 +644,13 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
           // with self-validating words it no longer does (222.5 vs 222.0; n = 1500: 58.3 vs 64.5).
           s->la_xhelper = 0;
         }
-        if (const char *e = getenv("AQ_LA_XHELPER")) s->la_xhelper = atoi(e) != 0;   // test hook
-        if (const char *e = getenv("AQ_XTOUCH")) s->la_xtouch = atoi(e) != 0;
-        s->la_nt3_pinned = getenv("AQ_NT3") != nullptr;
+        if (const char *e = aq_env(s, "AQ_LA_XHELPER")) s->la_xhelper = atoi(e) != 0;   // test hook
+        if (const char *e = aq_env(s, "AQ_XTOUCH")) s->la_xtouch = atoi(e) != 0;
+        if (const char *e = aq_env(s, "AQ_HPRIO")) s->la_hprio = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;
+        s->la_nt3_pinned = aq_env(s, "AQ_NT3") != nullptr;
         if (s->TT == 2) s->stagger = (s->NT + 2) / 3;
       }
-      if (const char *e = getenv("AQ_STAGGER")) s->stagger = atoi(e) >= 0 ? atoi(e) : 0;
+      if (const char *e = aq_env(s, "AQ_STAGGER")) s->stagger = atoi(e) >= 0 ? atoi(e) : 0;
       // more workgroups than CUs: chained SNP segments even out the last round (3 rounds -> ~2.5 for 625 workgroups)
       const int nwg = s->ntile / s->TT;
       if (nwg > s->ncu && s->laC == 1) {
@@ -646,7 +662,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         }
         if (best >= (double)((nwg + s->ncu - 1) / s->ncu)) s->chain = 0;   // no gain over whole tiles
       }
-      if (const char *e = getenv("AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
+      if (const char *e = aq_env(s, "AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
       if (s->chain > s->nb) s->chain = s->nb;
       if (s->chain > 32) s->chain = 32;
       if (s->laC > 1) s->chain = 0;   // the parts of a group must be co-resident: no chained segments
@@ -662,7 +678,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       }
       if (best >= (double)((s->ntile + s->ncu - 1) / s->ncu)) s->chain = 0;
     }
-    if (const char *e = getenv("AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
+    if (const char *e = aq_env(s, "AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
     if (s->chain > s->nb) s->chain = s->nb;
     if (s->chain > 32) s->chain = 32;
   }
@@ -1353,6 +1369,17 @@ extern "C" int aq_vb_get_status(aq_vb_handle s, aq_vb_status *st) {
   st->tiles_per_group = s->use_la ? s->TT : 1;
   st->chain_segments = s->chain > 1 ? s->chain : 0;
   return AQ_OK;
+}
+
+extern "C" int32_t aq_vb_get_overrides(aq_vb_handle s, char *buf, int32_t cap) {
+  if (!s) return -1;
+  const int32_t n = (int32_t)s->overrides.size();
+  if (buf && cap > 0) {
+    const int32_t m = n < cap - 1 ? n : cap - 1;
+    std::memcpy(buf, s->overrides.data(), (size_t)m);
+    buf[m] = 0;
+  }
+  return n;
 }
 
 extern "C" int32_t aq_vb_get_elbo_trace(aq_vb_handle s, int32_t *it_out, double *lb_out, int32_t cap) {

@@ -301,7 +301,8 @@ def main():
                        "annealed_sweeps_per_s": (args.warmup / t_warm) if t_warm else None,
                        "setup_s": round(t_setup, 1),
                        # the host's launch plan of the core kernel on rank 0 (aq_vb_status)
-                       "launch": {k: st1[k] for k in ("core_kernel", "split_parts", "tiles_per_group", "chain_segments")}},
+                       "launch": {k: st1[k] for k in ("core_kernel", "split_parts", "tiles_per_group", "chain_segments")},
+                       "env_overrides": st1["overrides"]},
             "roofline": {"bound": "mfma", "kernel": {0: "aq_core_sweep_la_kernel", 2: "aq_trait_wave_kernel",
                                                      3: "aq_core_sweep_mis_kernel"}[st1["core_kernel"]], "achieved": achieved,
                          "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,

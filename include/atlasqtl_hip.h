@@ -206,6 +206,11 @@ typedef struct aq_vb_status {
 } aq_vb_status;
 int aq_vb_get_status(aq_vb_handle h, aq_vb_status *st);
 
+/* The AQ_* environment variables (launch-plan overrides for tests and experiments: AQ_TT, AQ_CHAIN, AQ_LA_C, AQ_NT3, AQ_KERNEL, ...)
+ * that were SET when the handle was created, as "NAME=value NAME=value"; empty when the plan is the library's own.  Returns the
+ * length of the full string (buf may be NULL).  A host that inherits its environment (an R session) can check it here. */
+int32_t aq_vb_get_overrides(aq_vb_handle h, char *buf, int32_t cap);
+
 /* ELBO trace: up to cap (iteration, value) pairs in evaluation order; returns the count. */
 int32_t aq_vb_get_elbo_trace(aq_vb_handle h, int32_t *it_out, double *lb_out, int32_t cap);
 

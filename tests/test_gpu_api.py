@@ -337,3 +337,20 @@ def test_launch_plan_follows_the_problem_shape(monkeypatch):
     assert (k, tiles, chain) == (0, 1, 0) and parts >= 2
     monkeypatch.setenv("AQ_LA_NOSPLIT", "1")
     assert plan(1000, 64, 24) == (0, 1, 1, 0)
+
+
+def test_env_overrides_are_reported(monkeypatch):
+    """The AQ_* launch-plan hooks a handle was created under are visible through the C ABI (aq_vb_get_overrides): a host that
+    inherits its environment can tell that the plan is not the library's own."""
+    from atlasqtl_amd.core import VbRun
+    from tests.util import make_problem
+    prob = make_problem(100, 75, 20, p_act=5)
+    r = VbRun(prob["Y"], prob["X"], prob["list_hyper"], prob["list_init"], None, 0.1, 3)
+    assert r.status()["overrides"] == ""
+    r.close()
+    monkeypatch.setenv("AQ_CHAIN", "3")
+    monkeypatch.setenv("AQ_TT", "2")
+    r = VbRun(prob["Y"], prob["X"], prob["list_hyper"], prob["list_init"], None, 0.1, 3)
+    ov = r.status()["overrides"].split()
+    assert "AQ_CHAIN=3" in ov and "AQ_TT=2" in ov and len(ov) == 2
+    r.close()
