@@ -385,6 +385,33 @@ AQ_HD double aq_gamma_inc_upper(double a, double x) {
   return g1 + sum;
 }
 
+// Kummer's M(a; b; x) = 1F1 by its power series, for x > 0 and b not a non-positive integer (gsl::hyperg_1F1 at the call sites of
+// update_annealed_lam2_inv_vb_, R/update_vb.R:78-81: b in {3 - c, 2 - c, c, c - 1} with 0 < c < 1, so b = c - 1 is negative and not
+// an integer; every term after the first then has one sign).  Terms grow until k ~ x: good for the L of the path (order one);
+// beyond x ~ 700 it overflows as the reference's own expression does.
+AQ_HD double aq_hyp1f1_series(double a, double b, double x) {
+  double term = 1.0, sum = 1.0;
+  for (int k = 0; k < 4000; k++) {
+    term *= (a + k) / (b + k) * x / (double)(k + 1);
+    sum += term;
+    if (fabs(term) < 1e-17 * fabs(sum) && (double)k > x) break;
+  }
+  return sum;
+}
+// update_annealed_lam2_inv_vb_(L_vb, c, df) for df != 1 exactly as the reference writes it (R/update_vb.R:76-81): a quotient of two
+// differences of Kummer functions -- Gamma(a + 1) U(a + 1, 3 - c, L) / (Gamma(a) U(a, 2 - c, L)) / df with a = c (df - 1) / 2 + 1 in
+// Tricomi's U -- which cancels as L grows (the two terms of each difference grow like e^L, the difference falls like L^-a).
+// Reproduced term by term, not repaired: parity with the reference is the contract.
+AQ_HD double aq_annealed_lam2_inv_df(double L, double c, double df) {
+  const double a = c * (df - 1.0) / 2.0 + 1.0, ap = c * (df + 1.0) / 2.0;
+  const double gc = tgamma(c), gap = tgamma(ap);
+  const double num = tgamma(a + 1.0) * gc * aq_hyp1f1_series(a + 1.0, 3.0 - c, L) / (c - 1.0) / (c - 2.0) / gap +
+                     tgamma(2.0 - c) * pow(L, c - 2.0) * aq_hyp1f1_series(ap, c - 1.0, L);
+  const double den = tgamma(a) * gc * aq_hyp1f1_series(a, 2.0 - c, L) / (c - 1.0) / gap +
+                     tgamma(1.0 - c) * pow(L, c - 1.0) * aq_hyp1f1_series(ap, c, L);
+  return num / den / df;
+}
+
 // Inverse Mills ratios and the probit auxiliary mean Z of one (j,k) entry,
 // R/update_vb.R:217-234 with R/utils.R:172-191.  U = sqrt_c*u, lP = log Phi(U), l1 = log(1-Phi(U)).
 AQ_HD double aq_probit_z(double gam, double u, double U, double lP, double l1, double sqrt_c) {

@@ -459,7 +459,10 @@ __global__ void aq_k_pvec_finish(AqPvec v, AqScalars *sc, double c, double c_s, 
   if (j < v.p) {
     double L = v.L[j];
     double lam;
-    if (annealing) {
+    if (annealing && v.df != 1.0) {
+      lam = aq_annealed_lam2_inv_df(L, c_s, v.df);                                   // R/update_vb.R:76-81 (Kummer's 1F1)
+      v.Q[j] = 0.0;
+    } else if (annealing) {
       // gsl::gamma_inc(2-c, L) / (gsl::gamma_inc(1-c, L) L) - 1, with Gamma(a+1,x) = a Gamma(a,x) + x^a e^-x
       double aa = 1.0 - c_s;
       double ga = aq_gamma_inc_upper(aa, L);

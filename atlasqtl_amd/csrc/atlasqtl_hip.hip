@@ -441,8 +441,6 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
   const int df = pr->df == 0 ? 1 : pr->df;
   if (pr->scheme == 0 && df != 1 && df != 3 && df != 5 && df != 7)
     return aq_fail(AQ_ERR_UNSUPPORTED, "df must be 1, 3, 5 or 7 (the reference calls compute_integral_hs_ unstable from df = 9 on, R/utils.R:510)");
-  if (pr->scheme == 0 && df != 1 && pr->has_anneal)
-    return aq_fail(AQ_ERR_UNSUPPORTED, "df > 1 with annealing needs Kummer's 1F1 in update_annealed_lam2_inv_vb_ (R/update_vb.R:76-81): not built");
   AQ_TRY(aq_need_device(pr->device));
 
   // X must be complete; Y may hold NaN.  With xy_on_device both are device pointers: X is trusted to be the standardised
@@ -1584,6 +1582,10 @@ __host__ __device__ static inline bool aq_special_one(int which, double x, doubl
     case 16: *out = aq_hs_integral(7.0, 7.0 * x, 4, 4, x2); return true;
     case 17: *out = aq_hs_integral(7.0, 7.0 * x, 4, 3, x2); return true;
     // the table-driven probit terms of the sweep kernel's helper wave (aq_probit_tab.h): A, imr1, imr0
+    // update_annealed_lam2_inv_vb_ for df = 3, 5, 7 (R/update_vb.R:76-81): x = L_vb, x2 = c
+    case 21: *out = aq_annealed_lam2_inv_df(x, x2, 3.0); return true;
+    case 22: *out = aq_annealed_lam2_inv_df(x, x2, 5.0); return true;
+    case 23: *out = aq_annealed_lam2_inv_df(x, x2, 7.0); return true;
     case 18: aq_probit_A_imr_tab(x, aq_pt_table(), &a_, &b_, &c_); *out = a_; return true;
     case 19: aq_probit_A_imr_tab(x, aq_pt_table(), &a_, &b_, &c_); *out = b_; return true;
     case 20: aq_probit_A_imr_tab(x, aq_pt_table(), &a_, &b_, &c_); *out = c_; return true;
@@ -1593,7 +1595,7 @@ __host__ __device__ static inline bool aq_special_one(int which, double x, doubl
 
 extern "C" int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len) {
   if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval: bad argument");
-  if ((which == 3 || (which >= 14 && which <= 17)) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
+  if ((which == 3 || (which >= 14 && which <= 17) || which >= 21) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
   for (int64_t i = 0; i < len; i++)
     if (!aq_special_one(which, x[i], x2 ? x2[i] : 0.0, &out[i])) return aq_fail(AQ_ERR_ARG, "aq_special_eval: unknown function id");
   return AQ_OK;
@@ -1606,8 +1608,8 @@ __global__ void aq_k_special_eval(int which, const double *x, const double *x2, 
 
 extern "C" int aq_special_eval_device(int32_t which, const double *x, const double *x2, double *out, int64_t len, int32_t device) {
   if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: bad argument");
-  if (which < 0 || which > 20) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: unknown function id");
-  if ((which == 3 || (which >= 14 && which <= 17)) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: x2 required");
+  if (which < 0 || which > 23) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: unknown function id");
+  if ((which == 3 || (which >= 14 && which <= 17) || which >= 21) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: x2 required");
   AQ_TRY(aq_need_device(device));
   if (len == 0) return AQ_OK;
   double *dx = nullptr, *dx2 = nullptr, *dout = nullptr;

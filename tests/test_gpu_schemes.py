@@ -60,13 +60,38 @@ def test_horseshoe_df_3_5_7_matches_oracle(shape, na, df):
     np.testing.assert_allclose(got["lam2_inv_vb"], ref["lam2_inv_vb"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("anneal", [(1, 2, 10), (2, 3, 5)])
+@pytest.mark.parametrize("shape,na", [((100, 75, 20), 0.0), ((200, 90, 33), 0.08)])
+@pytest.mark.parametrize("df", [3, 5, 7])
+def test_horseshoe_df_3_5_7_with_annealing_matches_oracle(shape, na, df, anneal):
+    """df > 1 under the reference's DEFAULT anneal = c(1, 2, 10): update_annealed_lam2_inv_vb_ with Kummer's 1F1
+    (R/update_vb.R:76-81; the oracle takes 1F1 from scipy.special.hyp1f1, the device from its power series)."""
+    import atlasqtl_amd as A
+    from oracle import atlasqtl_oracle as O
+    n, p, q = shape
+    prob = make_problem(n, p, q, p_act=8, prob_assoc=1.0 if q <= 20 else 0.3, na_frac=na)
+    tr = []
+    ref = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, df, 0.1, 1000, prob["list_hyper"], prob["list_init"], trace=tr,
+                                        full_output=True)
+    got = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, df, 0.1, 1000, 0, prob["list_hyper"], prob["list_init"],
+                                        full_output=True, debug=True)
+    _compare(ref, got, tr, rtol_scale=1e-9 if df == 3 else 1e-7)
+    np.testing.assert_allclose(got["lam2_inv_vb"], ref["lam2_inv_vb"], rtol=1e-6)
+    # ... and the state right after the ladder (the annealed update itself, before any ELBO evaluation)
+    k = int(anneal[2]) - 1
+    r2 = O.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, df, 0.1, k, prob["list_hyper"], prob["list_init"], full_output=True)
+    g2 = A.atlasqtl_global_local_core_(prob["Y"], prob["X"], q, anneal, df, 0.1, k, 0, prob["list_hyper"], prob["list_init"],
+                                       full_output=True, debug=True)
+    np.testing.assert_allclose(g2["lam2_inv_vb"], r2["lam2_inv_vb"], rtol=1e-8)
+    np.testing.assert_allclose(g2["theta_vb"], r2["theta_vb"], rtol=1e-7, atol=1e-10)
+
+
 def test_unsupported_variants_fail_loudly():
     import atlasqtl_amd as A
     from atlasqtl_amd._lib import AtlasqtlHipError
     prob = make_problem(100, 40, 8, p_act=4, prob_assoc=1.0)
-    with pytest.raises(AtlasqtlHipError, match="Kummer"):
-        A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 8, (1, 2, 10), 3, 0.1, 10, 0, prob["list_hyper"], prob["list_init"])
-    with pytest.raises(AtlasqtlHipError, match="Kummer"):
-        A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 8, (1, 2, 10), 5, 0.1, 10, 0, prob["list_hyper"], prob["list_init"])
+    with pytest.raises(AtlasqtlHipError, match="df must be 1, 3, 5 or 7"):
+        from atlasqtl_amd.core import VbRun
+        VbRun(prob["Y"], prob["X"], prob["list_hyper"], prob["list_init"], None, 0.1, 10, df=4)
     with pytest.raises(NotImplementedError, match="df must be 1, 3, 5 or 7"):
         A.atlasqtl_global_local_core_(prob["Y"], prob["X"], 8, None, 9, 0.1, 10, 0, prob["list_hyper"], prob["list_init"])

@@ -181,3 +181,28 @@ def test_probit_tables_against_mpmath():
             a, b = ev(w, np.array([lo, hi, -lo, -hi]))[[0, 1]], ev(w, np.array([lo, hi, -lo, -hi]))[[2, 3]]
             assert abs(a[0] - a[1]) < 1e-13 * max(1.0, abs(a[0])) and abs(b[0] - b[1]) < 1e-13 * max(1.0, abs(b[0]))
     assert np.all(np.isnan(ev(18, np.array([np.nan]))))
+
+
+def test_annealed_lam2_inv_df_gt_1_against_tricomi_u():
+    """update_annealed_lam2_inv_vb_ for df = 3, 5, 7 (R/update_vb.R:76-81).  In Tricomi's U the reference's quotient is
+    a U(a + 1, 3 - c, L) / (df U(a, 2 - c, L)), a = c (df - 1) / 2 + 1.  The reference writes each U as a DIFFERENCE of two Kummer
+    functions that grow like e^L while the difference falls like L^-a, so its own expression loses digits as L grows -- measured
+    here for the oracle's restatement (scipy.special.hyp1f1) and for the device's (power series) against 60-digit mpmath.hyperu:
+    ~1e-11 up to L = 2 (where the runs live: L is of order one during the ladder), ~1e-7 up to 6, nothing left beyond 10.
+    The device reproduces the expression term by term, as everywhere: the bars are those of the expression, not tighter."""
+    import mpmath as mp
+    mp.mp.dps = 60
+    rng = np.random.default_rng(3)
+    for which, df in ((21, 3), (22, 5), (23, 7)):
+        L = np.concatenate([rng.uniform(0.01, 2.0, 300), rng.uniform(2.0, 6.0, 100)])
+        c = rng.uniform(0.5, 0.93, L.size)                     # the ladder of anneal = c(1, 2, 10) ends at 2^(-1/9) = 0.926
+        got = ev(which, L, c)
+        ref = np.array([float(mp.mpf(ci) * (df - 1) / 2 + 1) * float(mp.hyperu(ci * (df - 1) / 2 + 2, 3 - ci, li) /
+                                                                    mp.hyperu(ci * (df - 1) / 2 + 1, 2 - ci, li)) / df
+                        for li, ci in zip(L.tolist(), c.tolist())])
+        orc = np.array([O.update_annealed_lam2_inv_vb_(np.array([li]), ci, df)[0] for li, ci in zip(L, c)])
+        for lo, hi, tol in ((0, 2, 1e-9), (2, 6, 1e-5)):
+            m = (L >= lo) & (L < hi)
+            assert np.max(np.abs(got[m] - ref[m]) / np.abs(ref[m])) < tol, (df, lo)
+            assert np.max(np.abs(got[m] - orc[m]) / np.abs(orc[m])) < tol, (df, lo)
+        assert np.all(np.isfinite(ev(which, np.array([20.0, 100.0, 600.0]), np.array([0.7, 0.7, 0.7]))))
