@@ -76,6 +76,7 @@ struct AqCoreArgs {
   const double *zeta;
   double sqrt_c;         // annealing: the Mills ratios are taken at sqrt(c) (theta_j + zeta_k), R/update_vb.R:219-224
   int c_is_one;
+  int mprio;             // look-ahead kernel: matrix waves run their hand-offs (everything outside the MFMA stream) at raised priority
   int hprio;             // look-ahead kernel: s_setprio level of the helper wave (its fp64 VALU work shares SIMD 3 with the recurrence wave's MFMAs)
 };
 

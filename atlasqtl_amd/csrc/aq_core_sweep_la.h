@@ -434,6 +434,11 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
       for (int tt = 0; tt < TT; tt++) acc[tt] = (aq_d4){0, 0, 0, 0};
       const char *xu = XUb + __builtin_amdgcn_readfirstlane(bu) * BLK, *xa = XAb + __builtin_amdgcn_readfirstlane(bs) * BLK;
       const char *nxu = XUb + __builtin_amdgcn_readfirstlane(nbu) * BLK, *nxa = XAb + __builtin_amdgcn_readfirstlane(nbs) * BLK;
+      // Two matrix waves share a SIMD.  At equal priority the one that streams MFMAs wins every issue slot and its partner's
+      // hand-off work (counter polls, the delta read, address arithmetic: a few dozen VALU operations) only advances in the
+      // stream's gaps -- the two loops ran strictly one after the other, hand-offs included.  So a matrix wave runs its hand-offs
+      // at raised priority (they slip between the partner's MFMAs) and drops back for its own MFMA stream.
+      if (ROLE != 2 && a.mprio) __builtin_amdgcn_s_setprio(0);
       auto U = [&](auto tc, aq_v2 u0, aq_v2 u1) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value;
         aq_static_for<TT>([&](auto ttc) __attribute__((always_inline)) {
@@ -555,6 +560,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           __builtin_amdgcn_sched_barrier(0);
         });
       }
+      if (ROLE != 2 && a.mprio) __builtin_amdgcn_s_setprio(2);
       if (do_s) {
         const int ps = bs & 1;
 #pragma unroll

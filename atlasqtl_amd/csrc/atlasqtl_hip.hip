@@ -167,6 +167,7 @@ struct aq_vb {
   int la_xtouch = 1;        // helper waves warm the L2 with the next phase's X operand panels (AQ_XTOUCH=0 switches it off)
   bool la_nt3_pinned = false;   // AQ_NT3 given: the annealed sweeps keep the geometry as well
   int NT3x = -1;                // look-ahead kernel, two-tile instances: 9 residual tiles on the recurrence wave (geometry NT / NT / 9), -1 = aq_la_nt3
+  int la_mprio = 1;         // matrix waves: hand-offs at raised priority (AQ_MPRIO=0 switches it off): C3 34.84 -> 34.67 ms, C3 + 5 % NA 49.9 -> 47.1
   int la_hprio = 0;         // s_setprio level of the helper wave (AQ_HPRIO)
   int la_xhelper = 0;       // sample split of the look-ahead kernel: exchange on the helper wave (long matrix phases) or on the recurrence wave
   int chain = 0;            // > 1: chained-segment launch with that many SNP segments (aq_core_sweep_la.h, SEG)
@@ -331,6 +332,7 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     a.C = s->laC; a.xhelper = s->la_xhelper; a.Pbuf = s->Pbuf; a.pflag = s->pflag; a.rnpart = s->rnpart;
     a.xtouch = s->la_xtouch;
     a.hprio = s->la_hprio;
+    a.mprio = s->la_mprio;
     a.mis = s->mis; a.GK = s->GK; a.tau = s->tau; a.log_tau = s->log_tau;
     a.sig2_inv_p = &s->sc->sig2_inv; a.log_sig2_inv_p = &s->sc->log_sig2_inv;
     if (s->laC > 1 && (!a.Pbuf || !a.rnpart || !a.errflag)) return aq_fail(AQ_ERR_DEVICE, "sample split without its exchange buffers");
@@ -644,6 +646,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         }
         if (const char *e = aq_env(s, "AQ_LA_XHELPER")) s->la_xhelper = atoi(e) != 0;   // test hook
         if (const char *e = aq_env(s, "AQ_XTOUCH")) s->la_xtouch = atoi(e) != 0;
+        if (const char *e = aq_env(s, "AQ_MPRIO")) s->la_mprio = atoi(e) != 0;
         if (const char *e = aq_env(s, "AQ_HPRIO")) s->la_hprio = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;
         s->la_nt3_pinned = aq_env(s, "AQ_NT3") != nullptr;
         if (s->TT == 2) s->stagger = (s->NT + 2) / 3;
