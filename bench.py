@@ -37,10 +37,10 @@ PEAK_FP64_MFMA_MEASURED_TFLOPS = 77.8
 # HBM-side bytes of ONE core-sweep launch at the default workload on one GPU, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command with the gfx950
 # correction (FETCH_SIZE x 2 for coalesced streaming reads, calibrated on aq_k_prepass's gam read):
-# profiles/r02_pmc_hbm_traffic_v6.txt (the post-annealing instance <10, 9, true, 2>: reads 2 x 12,875,608 KiB + writes 8,430,415 KiB;
+# profiles/r03_pmc_hbm_traffic.txt (the instance <10, 9, true, 2>: reads 2 x 13,079,158 KiB + writes 8,389,826 KiB;
 # the reads include the helper waves' L2 warm-up touches).  PMC counters cannot be read from inside the timed run, so this is the
 # profile's number for the same kernel and workload, not a value measured in this run.
-PMC_TRAFFIC_C3_BYTES = 3.50e10
+PMC_TRAFFIC_C3_BYTES = 3.54e10
 # the same workload with 5 % of Y missing (AQ_BENCH_NA=0.05: the MASK instance of the look-ahead kernel, which streams the
 # traits' own Gram blocks, 98 GB per sweep): profiles/r02_pmc_hbm_traffic_c3_na5_v5.txt (2 x 72,413,656 KiB + 8,769,794 KiB)
 PMC_TRAFFIC_C3_NA5_BYTES = 1.57e11
@@ -307,7 +307,7 @@ def main():
                                                      3: "aq_core_sweep_mis_kernel"}[st1["core_kernel"]], "achieved": achieved,
                          "peak": PEAK_FP64_SPEC_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_SPEC_TFLOPS,
                          "traffic": pmc_traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC passes of the same command, profiles/r02_pmc_hbm_traffic_*.txt: a profile constant, not measured in this run)",
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC passes of the same command, profiles/r03_pmc_hbm_traffic*.txt: a profile constant, not measured in this run)",
                          "algorithmic_bytes": algo_bytes,
                          "peak_measured_mfma_f64": PEAK_FP64_MFMA_MEASURED_TFLOPS,
                          "frac_of_measured_mfma_peak": achieved / PEAK_FP64_MFMA_MEASURED_TFLOPS,

@@ -1,7 +1,7 @@
 # Profile pass of the default bench workload (C3, 1 x MI355X): kernel stats, then FETCH_SIZE and WRITE_SIZE in separate --pmc runs
 # (MI355X_MICROARCH.md, HBM section).  usage (on the GPU box): bash tools/prof_bench.sh <tag>   -> gpurun_out/<tag>/
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats -- python bench.py --steps 10 --warmup 10 --no-cpu-baseline --no-to-tol > gpurun_out/$TAG/stats.log 2>&1
