@@ -42,8 +42,8 @@ PEAK_FP64_MFMA_MEASURED_TFLOPS = 77.8
 # profile's number for the same kernel and workload, not a value measured in this run.
 PMC_TRAFFIC_C3_BYTES = 3.54e10
 # the same workload with 5 % of Y missing (AQ_BENCH_NA=0.05: the MASK instance of the look-ahead kernel, which streams the
-# traits' own Gram blocks, 98 GB per sweep): profiles/r02_pmc_hbm_traffic_c3_na5_v5.txt (2 x 72,413,656 KiB + 8,769,794 KiB)
-PMC_TRAFFIC_C3_NA5_BYTES = 1.57e11
+# traits' own Gram blocks, 98 GB per sweep): profiles/r03_pmc_hbm_traffic_c3_na5.txt (2 x 64,915,347 KiB + 8,789,477 KiB)
+PMC_TRAFFIC_C3_NA5_BYTES = 1.42e11
 
 
 def build_problem(n, p, q_total, k0, k1, device, seed=123):
