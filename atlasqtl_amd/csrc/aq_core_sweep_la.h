@@ -242,7 +242,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   // never stop at a barrier.  LDS operations of a wave execute in order and the LDS is one pipeline per CU, so
   // "data stores; s_waitcnt lgkmcnt(0); counter store" on one side and "counter load ... ; data loads" on the other are
   // ordered; the asm memory clobbers keep the compiler from moving accesses across them.
-  __shared__ int Fl[16];
+  __shared__ __attribute__((aligned(16))) int Fl[16];
   // (explicit LDS address space: through a generic pointer the volatile accesses become flat loads with a vmcnt(0) drain)
   typedef __attribute__((address_space(3))) volatile int aq_lds_vint;
   aq_lds_vint *Flv = (aq_lds_vint *)(__attribute__((address_space(3))) int *)Fl;
@@ -254,7 +254,8 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
   long long dg_wait = 0, dg_wait_b = 0;   // waits on the matrix / recurrence counters; on the helper's and the stagger counters
   const long long dg_t0 = __builtin_readcyclecounter();
 #endif
-#ifdef AQ_DIAG_TIME
+#if defined(AQ_DIAG_TIME) || defined(AQ_DIAG_TL)   // (AQ_DIAG_TL: the timeline marks alone -- a lighter build for instances whose
+                                                    // registers the wait counters would push over the edge)
   // timeline of workgroup 0, phases 64 .. 95: slot k of (wave, phase) <- cycle counter (behind the per-wave counters in a.dbg)
   auto tl_mark = [&](int i, int k) __attribute__((always_inline)) {
     if (a.dbg && blockIdx.x == 0 && i >= 64 && i < 96 && lane == 0)
@@ -272,6 +273,26 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
 #ifdef AQ_DIAG_TIME
     if (idx >= 7) dg_wait_b += __builtin_readcyclecounter() - t_in;
     else dg_wait += __builtin_readcyclecounter() - t_in;
+#endif
+  };
+  // the recurrence wave's wait at the top of a chain -- all six matrix waves' partial S' and the helper's staging -- as ONE poll of
+  // two 16-byte LDS reads instead of seven round trips in a row (0.3 us per SNP block where the chain is the critical path)
+  typedef int aq_i4 __attribute__((ext_vector_type(4)));
+  auto wait_s_and_staged = [&](int val) __attribute__((always_inline)) {
+    typedef __attribute__((address_space(3))) volatile aq_i4 aq_lds_vi4;
+    aq_lds_vi4 *fp = (aq_lds_vi4 *)(__attribute__((address_space(3))) int *)Fl;
+#ifdef AQ_DIAG_TIME
+    const long long t_in = __builtin_readcyclecounter();
+#endif
+    for (;;) {
+      const aq_i4 f0 = fp[0], f1 = fp[1];   // Fl[0..3], Fl[4..7]; Fl[6] is this wave's own counter
+      const int lo = min(min(min(f0.x, f0.y), min(f0.z, f0.w)), min(min(f1.x, f1.y), f1.w));
+      if (lo >= val) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+#ifdef AQ_DIAG_TIME
+    dg_wait += __builtin_readcyclecounter() - t_in;
 #endif
   };
   if (tid < 16) Fl[tid] = 0;
@@ -697,9 +718,7 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           for (int r = 0; r < RPG; r++) Sown[r] = Stot[par][(hg + NG * r) * NTR + ht];
         } else {
           // block b needs its six partial S' and its staged scalars
-#pragma unroll
-          for (int m = 0; m < NWM; m++) wait_ge(m, need);
-          wait_ge(7, need);
+          wait_s_and_staged(need);
 #pragma unroll
           for (int r = 0; r < RPG; r++) {
             const int j = hg + NG * r;
