@@ -1001,22 +1001,34 @@ __global__ __launch_bounds__(8 * 64, 2) void aq_core_sweep_la_kernel(const AqCor
           st_Gx[r] = a.Gx[(size_t)bx * 256 + lane + 64 * r];
         }
       }
+      // MASK: the per-entry constants of the NA forms -- a reciprocal and a logarithm per entry, each a chain of dependent fp64
+      // operations -- for all entries of the lane at once, so that the RPG chains interleave (inside the table passes below every
+      // entry sits between scheduling barriers and its chain would run alone; this wave's iteration is on the critical cycle of
+      // the MASK instances)
+      double ls2r[MASK ? RPG : 1];
+      if constexpr (MASK) {
+#pragma unroll
+        for (int r = 0; r < RPG; r++) {
+          const int e = lane + 64 * r;
+          const double is2 = a.c * (st_xn[r] + sig2_inv_h) * tau_k;            // update_sig2_beta_vb_ with X_norm_sq, R/update_vb.R:45
+          const double s2 = aq_recip_pos(is2);
+          const double ls2 = -aq_log_pos(is2);
+          const double cf = a.c * s2 * tau_k;                                  // src/coreLoop.cpp:125
+          Lcoef[par][e] = cf;
+          LK[par][e] = cf * cf * (a.c * 0.5 * is2);                            // coef^2 c / (2 sig2_beta), 1 / sig2_beta = is2: x = cA - s^2 K
+          Ls2[par][e] = s2;
+          Lls2[par][e] = ls2;
+          Lxn[par][e] = st_xn[r];
+          ls2r[r] = ls2;
+        }
+      }
       // A(u), the slope b = imr1 - imr0 and the intercept a = u + imr0 of Z (at U = sqrt(c) u, over sqrt(c), when annealing:
       // R/update_vb.R:219-233), u = theta_j + zeta_k, for the RPG entries of this lane.
       auto emitA = [&](int r, double A) __attribute__((always_inline)) {
         const int j = 16 * b + hg + NG * r, e = lane + 64 * r;
         const bool valid = kvalid && j < a.p;
         if constexpr (MASK) {
-          const double is2 = a.c * (st_xn[r] + sig2_inv_h) * tau_k;            // update_sig2_beta_vb_ with X_norm_sq, R/update_vb.R:45
-          const double s2 = aq_recip_pos(is2);
-          const double ls2 = -aq_log_pos(is2);
-          const double cf = a.c * s2 * tau_k;                                  // src/coreLoop.cpp:125
-          LA[par][e] = a.c * ((valid ? A : 0.0) - 0.5 * ls2 + cstna_k);        // :127-129
-          Lcoef[par][e] = cf;
-          LK[par][e] = cf * cf * (a.c * 0.5 / s2);                             // coef^2 c / (2 sig2_beta): x = cA - s^2 K
-          Ls2[par][e] = s2;
-          Lls2[par][e] = ls2;
-          Lxn[par][e] = st_xn[r];
+          LA[par][e] = a.c * ((valid ? A : 0.0) - 0.5 * ls2r[r] + cstna_k);    // src/coreLoop.cpp:127-129
         } else {
           LA[par][e] = a.c * ((valid ? A : 0.0) + cst_k);                        // c (log(1-Phi) - log Phi + cst), src/coreLoop.cpp:75-77
         }

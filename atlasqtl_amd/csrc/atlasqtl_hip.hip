@@ -168,7 +168,7 @@ struct aq_vb {
   bool la_nt3_pinned = false;   // AQ_NT3 given: the annealed sweeps keep the geometry as well
   int NT3x = -1;                // look-ahead kernel, two-tile instances: 9 residual tiles on the recurrence wave (geometry NT / NT / 9), -1 = aq_la_nt3
   int la_mprio = 1;         // matrix waves: hand-offs at raised priority (AQ_MPRIO=0 switches it off): C3 34.84 -> 34.67 ms, C3 + 5 % NA 49.9 -> 47.1
-  int la_hprio = 0;         // s_setprio level of the helper wave (AQ_HPRIO)
+  int la_hprio = 0;         // s_setprio level of the helper wave (AQ_HPRIO; 1 for the unsplit MASK instances, see below)
   int la_xhelper = 0;       // sample split of the look-ahead kernel: exchange on the helper wave (long matrix phases) or on the recurrence wave
   int chain = 0;            // > 1: chained-segment launch with that many SNP segments (aq_core_sweep_la.h, SEG)
   int *done = nullptr, *errflag = nullptr;
@@ -646,6 +646,10 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         }
         if (const char *e = aq_env(s, "AQ_LA_XHELPER")) s->la_xhelper = atoi(e) != 0;   // test hook
         if (const char *e = aq_env(s, "AQ_XTOUCH")) s->la_xtouch = atoi(e) != 0;
+        // helper wave one priority level above the recurrence wave it shares SIMD 3 with -- only where its iteration is on the
+        // critical cycle: the unsplit MASK instances (single cross-block buffer; C3 + 5 % NA 49.9 -> 48.6 ms on one box, 48.4 -> 47.4
+        // on another; the split C5 shard 241.1 -> 242.0, complete Y the same within noise: profiles/r03_hprio_na.txt)
+        if (s->la_mask && s->laC <= 1) s->la_hprio = 1;
         if (const char *e = aq_env(s, "AQ_MPRIO")) s->la_mprio = atoi(e) != 0;
         if (const char *e = aq_env(s, "AQ_HPRIO")) s->la_hprio = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;
         s->la_nt3_pinned = aq_env(s, "AQ_NT3") != nullptr;
