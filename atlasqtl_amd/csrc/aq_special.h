@@ -267,6 +267,48 @@ AQ_HD void aq_probit_A_imr_tab(double x, const double *tab, double *A, double *i
   *imr1 = b - m;                             // M(-x)
 }
 
+// log Phi(x) and log(1 - Phi(x)) from the tables (the ELBO pass: R/elbo.R:10-34 reads both for every entry): tabA = the A part of
+// aq_pt_table(), tabN = aq_ptn_table() (N(v) = log Phi(v), v >= 0).  Beyond the tables the near side is -Phi(-v) > -2e-33: zero
+// next to the far side's <= -72, which the tail series gives.
+#if defined(__HIPCC__)
+__device__ static const double aq_ptn_dev[AQ_PT_N_LEN] = {AQ_PT_N_VALUES};
+#endif
+static const double aq_ptn_host[AQ_PT_N_LEN] = {AQ_PT_N_VALUES};
+AQ_HD const double *aq_ptn_table() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return aq_ptn_dev;
+#else
+  return aq_ptn_host;
+#endif
+}
+template <class T>
+AQ_HD void aq_log_ndtr_pair_tab(double x, const T *tabA, const T *tabN, double *lP, double *l1) {
+  const double v = fabs(x);
+  const double t = v * (1.0 / AQ_PT_W);
+  const bool inside = v < AQ_PT_R;            // false for NaN as well
+  const int i = (int)fmin(t, (double)(AQ_PT_NI - 1));
+  const double xl = inside ? fma(2.0, t - (double)i, -1.0) : 0.0;
+  const T *pA = tabA + i, *pN = tabN + i;
+  constexpr int S = AQ_PT_NI;
+  double pa = pA[AQ_PT_DEG * S], pn = pN[AQ_PT_DEG * S];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k = AQ_PT_DEG - 1; k >= 0; k--) {
+    pa = fma(pa, xl, pA[k * S]);
+    pn = fma(pn, xl, pN[k * S]);
+  }
+  double Apos = pa, near_ = pn;               // A(v) = log Phi(-v) - log Phi(v) <= 0, N(v) = log Phi(v)
+  if (!inside) {
+    double tb, td;
+    aq_probit_tail(v, &Apos, &tb, &td);
+    near_ = (v != v) ? v : 0.0;              // (NaN stays NaN on both sides)
+  }
+  const double far_ = near_ + Apos;           // log Phi(-v)
+  *lP = x > 0.0 ? near_ : far_;
+  *l1 = x > 0.0 ? far_ : near_;
+}
+
 // log Phi(x) and log(1 - Phi(x)) = log Phi(-x) together.
 AQ_HD void aq_log_ndtr_pair(double x, double *lP, double *l1) {
   double i1, i0;

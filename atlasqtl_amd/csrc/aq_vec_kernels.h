@@ -208,6 +208,35 @@ __global__ __launch_bounds__(256) void aq_k_prepass(AqPrepass v) {
   double colA = 0.0, hacc = 0.0;
   int j0 = chunk * v.rows_per_chunk;
   int j1 = min(j0 + v.rows_per_chunk, v.p_pad);
+  if (!v.write_AB) {
+    // The ELBO's p x q part alone (the sweep kernel produces A, b and the sums of a itself): sum over the entries of
+    //   gam log Phi(u) + (1 - gam) log(1 - Phi(u)) - gam log(gam + eps) - (1 - gam) log(1 - gam + eps)        R/elbo.R:10-34
+    // log Phi and log(1 - Phi) from the tables (two Horner chains instead of erfcx + exp + log + log1p: 6.5 -> 2.x ms at C3), the
+    // entropy terms with the short logarithm.  The tables sit in LDS, coefficient-major: lanes in different intervals read
+    // different banks.
+    __shared__ double tA[AQ_PT_N_LEN], tN[AQ_PT_N_LEN];
+    for (int e = threadIdx.x; e < AQ_PT_N_LEN; e += 256) { tA[e] = aq_pt_dev[e]; tN[e] = aq_ptn_dev[e]; }
+    __syncthreads();
+    if (v.do_H && kvalid) {
+      for (int j = j0 + hj; j < j1 && j < v.p; j += 16) {
+        const size_t off = ((size_t)tile * v.p_pad + j) * 16 + hk;
+        const double g = v.gam[off];
+        double lP, l1;
+        aq_log_ndtr_pair_tab(v.theta[j] + zk, tA, tN, &lP, &l1);
+        hacc += g * lP + (1 - g) * l1 - g * aq_log_pos(g + eps) - (1 - g) * aq_log_pos(1 - g + eps);
+      }
+    }
+    if (v.do_H) {
+      sh[threadIdx.x] = hacc;
+      __syncthreads();
+      for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) v.Hpart[(size_t)tile * gridDim.x + chunk] = sh[0];
+    }
+    return;
+  }
   for (int j = j0 + hj; j < j1; j += 16) {
     size_t off = ((size_t)tile * v.p_pad + j) * 16 + hk;
     double A = 0.0, B = 0.0, aa = 0.0;

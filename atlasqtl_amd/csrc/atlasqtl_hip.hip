@@ -1596,13 +1596,16 @@ __host__ __device__ static inline bool aq_special_one(int which, double x, doubl
     case 18: aq_probit_A_imr_tab(x, aq_pt_table(), &a_, &b_, &c_); *out = a_; return true;
     case 19: aq_probit_A_imr_tab(x, aq_pt_table(), &a_, &b_, &c_); *out = b_; return true;
     case 20: aq_probit_A_imr_tab(x, aq_pt_table(), &a_, &b_, &c_); *out = c_; return true;
+    // log Phi(x), log(1 - Phi(x)) from the tables, as the ELBO pass takes them (aq_log_ndtr_pair_tab)
+    case 24: aq_log_ndtr_pair_tab(x, aq_pt_table(), aq_ptn_table(), &a_, &b_); *out = a_; return true;
+    case 25: aq_log_ndtr_pair_tab(x, aq_pt_table(), aq_ptn_table(), &a_, &b_); *out = b_; return true;
     default: return false;
   }
 }
 
 extern "C" int aq_special_eval(int32_t which, const double *x, const double *x2, double *out, int64_t len) {
   if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval: bad argument");
-  if ((which == 3 || (which >= 14 && which <= 17) || which >= 21) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
+  if ((which == 3 || (which >= 14 && which <= 17) || (which >= 21 && which <= 23)) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval: x2 required");
   for (int64_t i = 0; i < len; i++)
     if (!aq_special_one(which, x[i], x2 ? x2[i] : 0.0, &out[i])) return aq_fail(AQ_ERR_ARG, "aq_special_eval: unknown function id");
   return AQ_OK;
@@ -1615,8 +1618,8 @@ __global__ void aq_k_special_eval(int which, const double *x, const double *x2, 
 
 extern "C" int aq_special_eval_device(int32_t which, const double *x, const double *x2, double *out, int64_t len, int32_t device) {
   if (!x || !out || len < 0) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: bad argument");
-  if (which < 0 || which > 23) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: unknown function id");
-  if ((which == 3 || (which >= 14 && which <= 17) || which >= 21) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: x2 required");
+  if (which < 0 || which > 25) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: unknown function id");
+  if ((which == 3 || (which >= 14 && which <= 17) || (which >= 21 && which <= 23)) && !x2) return aq_fail(AQ_ERR_ARG, "aq_special_eval_device: x2 required");
   AQ_TRY(aq_need_device(device));
   if (len == 0) return AQ_OK;
   double *dx = nullptr, *dx2 = nullptr, *dout = nullptr;

@@ -306,6 +306,7 @@ int aq_vb_set_state(aq_vb_handle h, const void *buf, int64_t len);
  * 14 - 17 compute_integral_hs_ (x = L, x2 = Q(L)); 18 / 19 / 20 log(1-Phi) - log Phi and the two Mills ratios from the piecewise
  * polynomial tables the sweep kernel evaluates (aq_probit_tab.h; tail series beyond |x| = 12); 21 / 22 / 23
  * update_annealed_lam2_inv_vb_(x = L_vb, x2 = c, df = 3 / 5 / 7) (R/update_vb.R:76-81, Kummer's 1F1).
+ * 24 / 25 log Phi / log(1 - Phi) from the tables, as the ELBO pass (R/elbo.R:10-34) evaluates them (aq_log_ndtr_pair_tab).
  * Evaluates elementwise into out.  aq_special_eval_device runs the same switch in a kernel on `device`
  * (host pointers in and out): the device build of these functions (ocml, v_rcp_f64) is what the sweep executes.
  * ---------------------------------------------------------------------------------------- */

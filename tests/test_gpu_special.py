@@ -60,3 +60,17 @@ def test_probit_tables_on_device():
     for w in (18, 19, 20):                                   # host and device builds of the same header
         h, d = ev(w, x), evd(w, x)
         assert np.max(np.abs(h - d) / np.maximum(np.abs(h), 1.0)) < 2e-15
+
+
+def test_log_ndtr_pair_tables_on_device():
+    """Device build of the ELBO pass's log Phi / log(1 - Phi) (tables + tail series) against 60-digit mpmath and against the host build."""
+    from tests.test_special import _log_ndtr_pair_refs, probit_table_points, ev
+    x = probit_table_points()
+    lP, l1 = _log_ndtr_pair_refs(x)
+    gP, g1 = evd(24, x), evd(25, x)
+    assert np.max(np.abs(gP - lP) / np.maximum(np.abs(lP), 1.0)) < 4e-15
+    assert np.max(np.abs(g1 - l1) / np.maximum(np.abs(l1), 1.0)) < 4e-15
+    for w in (24, 25):
+        h, d = ev(w, x), evd(w, x)
+        assert np.max(np.abs(h - d) / np.maximum(np.abs(h), 1.0)) < 2e-15
+

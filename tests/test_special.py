@@ -183,6 +183,29 @@ def test_probit_tables_against_mpmath():
     assert np.all(np.isnan(ev(18, np.array([np.nan]))))
 
 
+def _log_ndtr_pair_refs(x):
+    import mpmath as mp
+    mp.mp.dps = 60
+    lP = np.array([float(mp.log(mp.erfc(-mp.mpf(float(v)) / mp.sqrt(2)) / 2)) for v in x])
+    l1 = np.array([float(mp.log(mp.erfc(mp.mpf(float(v)) / mp.sqrt(2)) / 2)) for v in x])
+    return lP, l1
+
+
+def test_log_ndtr_pair_tables_against_mpmath():
+    """log Phi(x) and log(1 - Phi(x)) as the ELBO pass takes them (aq_log_ndtr_pair_tab: the A table plus N(v) = log Phi(v),
+    tail series beyond |x| = 12; R/elbo.R:10-34 reads pnorm(., log.p = TRUE) of both tails) against 60-digit arithmetic: a few
+    ulp of max(|value|, 1) -- the near side is O(1e-33) beyond the tables and comes out as 0."""
+    x = probit_table_points()
+    lP, l1 = _log_ndtr_pair_refs(x)
+    gP, g1 = ev(24, x), ev(25, x)
+    assert np.max(np.abs(gP - lP) / np.maximum(np.abs(lP), 1.0)) < 4e-15
+    assert np.max(np.abs(g1 - l1) / np.maximum(np.abs(l1), 1.0)) < 4e-15
+    # the same two numbers from the closed forms the other kernels use
+    assert np.max(np.abs(gP - ev(5, x)) / np.maximum(np.abs(lP), 1.0)) < 4e-15
+    assert np.max(np.abs(g1 - ev(6, x)) / np.maximum(np.abs(l1), 1.0)) < 4e-15
+    assert np.all(np.isnan(ev(24, np.array([np.nan])))) and np.all(np.isnan(ev(25, np.array([np.nan]))))
+
+
 def test_annealed_lam2_inv_df_gt_1_against_tricomi_u():
     """update_annealed_lam2_inv_vb_ for df = 3, 5, 7 (R/update_vb.R:76-81).  In Tricomi's U the reference's quotient is
     a U(a + 1, 3 - c, L) / (df U(a, 2 - c, L)), a = c (df - 1) / 2 + 1.  The reference writes each U as a DIFFERENCE of two Kummer
