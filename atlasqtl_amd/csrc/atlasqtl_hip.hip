@@ -358,9 +358,8 @@ static int aq_launch_core(aq_vb *s, int mode, double c) {
     if (chained) AQ_HIP(hipMemsetAsync(s->done, 0, (size_t)s->ntile * sizeof(int), 0));
     // chained-segment launch: chain * nwg workgroups, workgroup s*nwg + k = SNP segment s of trait-tile group k
     const unsigned grid = chained ? (unsigned)((long long)s->chain * nwg) : nwg * (unsigned)s->laC;
-    // Annealed sweeps (c != 1): the helper wave evaluates the probit terms twice and SIMD 3 becomes the bound (42 ms against 35
-    // at C3), so the recurrence wave gives three of its six residual tiles back to the matrix waves: geometry (NT, NT, 3)
-    // instead of (NT, NT - 1, 6) -- the same 6 NT + 3 tiles, hence the same n_pad and residual layout in HBM (38.5 ms).
+    // One instance per handle for annealed and post-annealing sweeps alike: with the probit tables an annealed entry costs the
+    // same three polynomials as any other (round 2 swapped to a (NT, NT, 3) geometry for the annealed sweeps).
     int lrc = s->la_mask ? aq_la_launch_mask(s->NT, s->NT2, s->NT3x, chained, grid, 0, a)
               : s->TT == 2 ? aq_la_launch_tt2(s->NT, s->NT2, s->NT3x, chained, grid, 0, a) : aq_la_launch_tt1(s->NT, s->NT2, s->NT3x, chained, grid, 0, a);
     if (lrc != 0) return aq_fail(AQ_ERR_UNSUPPORTED, "no look-ahead kernel instantiation for this n");
