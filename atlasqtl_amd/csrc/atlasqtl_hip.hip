@@ -658,13 +658,16 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
       // more workgroups than CUs: chained SNP segments even out the last round (3 rounds -> ~2.5 for 625 workgroups)
       const int nwg = s->ntile / s->TT;
       if (nwg > s->ncu && s->laC == 1) {
+        // cost of a sweep in phases: rounds of workgroups x (SNP blocks of a segment + 2 phases of pipeline fill + ~1.7 of start-up:
+        // fitted to C3 at S = 4, 8, 13, 16, 26, profiles/r03_chain_segments.txt).  C3: 313 groups -> S = 13 (16 rounds of 241 blocks:
+        // 34.43 ms against 34.61 with S = 4); C3 with NA: 625 groups -> S = 9.
         double best = 1e30;
-        for (int S = 2; S <= 16; S++) {   // rounds of workgroups per sweep, in units of whole-sweep rounds
-          long long wg = (long long)nwg * S;
-          double cost = (double)((wg + s->ncu - 1) / s->ncu) / S * (1.0 + 0.002 * S);
-          if (cost < best - 1e-12) { best = cost; s->chain = S; }
+        for (int S = 2; S <= 32 && S <= s->nb; S++) {
+          const long long wg = (long long)nwg * S;
+          const double cost = (double)((wg + s->ncu - 1) / s->ncu) * ((s->nb + S - 1) / S + 3.7);
+          if (cost < best - 1e-9) { best = cost; s->chain = S; }
         }
-        if (best >= (double)((nwg + s->ncu - 1) / s->ncu)) s->chain = 0;   // no gain over whole tiles
+        if (best >= (double)((nwg + s->ncu - 1) / s->ncu) * (s->nb + 3.7)) s->chain = 0;   // no gain over whole tiles
       }
       if (const char *e = aq_env(s, "AQ_CHAIN")) s->chain = atoi(e) > 1 ? atoi(e) : 0;
       if (s->chain > s->nb) s->chain = s->nb;
