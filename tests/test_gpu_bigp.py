@@ -109,24 +109,25 @@ def test_c2_full_size_vs_nspace_oracle():
 @pytest.mark.parametrize("plan", ["host", "bench_instance", "trait_shard"])
 def test_c3_slice_vs_nspace_oracle(plan, monkeypatch):
     """(c): full C3 p (3125 SNP blocks) on a slice of 48 traits.  `bench_instance` = the kernel instance and launch form of
-    bench.py's C3 run -- <10, 9, SEG, 2>: two trait tiles per workgroup, 6 residual tiles on the recurrence wave, 4 chained SNP
-    segments of 781 blocks (on the annealed sweeps <10, 10, SEG, 2>) --, `trait_shard` = one tile per workgroup, chained, as a
-    q/N shard of a multi-GPU run launches it; `host` = whatever the library picks for 3 trait tiles (a sample split)."""
+    bench.py's C3 run -- <10, 9, SEG, 2>: two trait tiles per workgroup, 6 residual tiles on the recurrence wave, 13 chained SNP
+    segments of 241 blocks (the host's cost model at 313 groups on 256 CUs) --, `trait_shard` = one tile per workgroup, 13 segments, as
+    the q/2 shard of a two-GPU run launches it; `host` = whatever the library picks for 3 trait tiles (a sample split)."""
+    nseg = 13
     if plan == "bench_instance":
         monkeypatch.setenv("AQ_TT", "2")
-        monkeypatch.setenv("AQ_CHAIN", "4")
+        monkeypatch.setenv("AQ_CHAIN", str(nseg))
     elif plan == "trait_shard":
         monkeypatch.setenv("AQ_TT", "1")
         monkeypatch.setenv("AQ_LA_NOSPLIT", "1")
-        monkeypatch.setenv("AQ_CHAIN", "4")
+        monkeypatch.setenv("AQ_CHAIN", str(nseg))
     prob, ref, tr = _nspace_ref("c3", (1000, 50000, 48), 0.0, 12, p_act=60, prob_assoc=0.3)
     got = _gpu_run(prob, (1, 2, 10), 12)
     st = got["status"]
     assert st["core_kernel"] == 0
     if plan == "bench_instance":
-        assert st["tiles_per_group"] == 2 and st["chain_segments"] == 4
+        assert st["tiles_per_group"] == 2 and st["chain_segments"] == nseg
     elif plan == "trait_shard":
-        assert st["tiles_per_group"] == 1 and st["chain_segments"] == 4 and st["split_parts"] == 1
+        assert st["tiles_per_group"] == 1 and st["chain_segments"] == nseg and st["split_parts"] == 1
     _check(ref, got, tr, prob)
 
 
