@@ -572,10 +572,18 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         auto fit = [&](int tiles_needed, int nt_max, int *NTo, int *NT2o, int *N3xo) {
           int best_tiles = 1 << 30, best_nt3 = -1;
           for (int NT = 1; NT <= nt_max; NT++)
-            for (int NT2 = NT; NT2 >= (NT > 1 ? NT - 1 : NT); NT2--)
-              // x9: the instance NT / NT / 9 -- measured slower at C3 than 10 / 9 / 6 (38.5 against 35.0 ms: the helper wave's fp64
-              // work crawls while the recurrence wave's MFMAs hold SIMD 3's datapath), so only on request (AQ_NT3=9)
-              for (int x9 = 0; x9 <= ((s->TT == 2 && NT >= 8 && NT2 == NT && e3 && atoi(e3) == 9) ? 1 : 0); x9++) {
+            for (int NT2 = NT; NT2 >= (NT > 1 ? NT - 1 : NT); NT2--) {
+              // x9: the instance NT / NT / 9 -- nine residual tiles on the recurrence wave, 18 instead of 19 per matrix SIMD at
+              // n = 1000.  While the recurrence wave's MFMAs hold SIMD 3's datapath the helper wave's fp64 work crawls (38.4 ms at C3
+              // against 34.3 for 10 / 9 / 6), so it comes with the helper wave one priority level up (set below): 33.9 ms
+              // (profiles/r03_nt9_stagger.txt).  AQ_NT3 pins another count; the diagnostic build, whose NT / NT / 9 instances do not
+              // pass the ISA proof, takes it only on request.
+#ifdef AQ_DIAG_TIME
+              const bool x9_ok = s->TT == 2 && NT >= 8 && NT2 == NT && e3 && atoi(e3) == 9;
+#else
+              const bool x9_ok = s->TT == 2 && NT >= 8 && NT2 == NT && (!e3 || atoi(e3) == 9);
+#endif
+              for (int x9 = 0; x9 <= (x9_ok ? 1 : 0); x9++) {
                 int nt3 = x9 ? 9 : aq_la_nt3(NT, NT2, s->TT);
                 // one tile per workgroup, unsplit (the trait shards of N = 2, 4: MFMA-bound on three SIMDs while SIMD 3 only runs
                 // the chain): three residual tiles on the recurrence wave by default -- q = 5000: 19.55 -> 18.78 ms, q = 2500:
@@ -598,6 +606,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
                 if (tiles < tiles_needed || (e3 && atoi(e3) != nt3 && s->TT == 2 && NT >= 8)) continue;
                 if (tiles < best_tiles || (tiles == best_tiles && nt3 > best_nt3)) { best_tiles = tiles; best_nt3 = nt3; *NTo = NT; *NT2o = NT2; *N3xo = x9 ? 9 : x1; }
               }
+            }
           return best_tiles;
         };
         if (pr->n <= 1056 && !aq_env(s, "AQ_LA_C")) {
@@ -649,6 +658,7 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         // critical cycle: the unsplit MASK instances (single cross-block buffer; C3 + 5 % NA 49.9 -> 48.6 ms on one box, 48.4 -> 47.4
         // on another; the split C5 shard 241.1 -> 242.0, complete Y the same within noise: profiles/r03_hprio_na.txt)
         if (s->la_mask && s->laC <= 1) s->la_hprio = 1;
+        if (s->TT == 2 && s->NT3x == 9) s->la_hprio = 1;   // nine tiles on the recurrence wave: see fit()
         if (const char *e = aq_env(s, "AQ_MPRIO")) s->la_mprio = atoi(e) != 0;
         if (const char *e = aq_env(s, "AQ_HPRIO")) s->la_hprio = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;
         s->la_nt3_pinned = aq_env(s, "AQ_NT3") != nullptr;

@@ -37,10 +37,10 @@ PEAK_FP64_MFMA_MEASURED_TFLOPS = 77.8
 # HBM-side bytes of ONE core-sweep launch at the default workload on one GPU, from separate
 # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command with the gfx950
 # correction (FETCH_SIZE x 2 for coalesced streaming reads, calibrated on aq_k_prepass's gam read):
-# profiles/r03_pmc_hbm_traffic.txt (the instance <10, 9, true, 2> with 13 chained segments: reads 2 x 14,356,679 KiB + writes 9,110,537 KiB;
+# profiles/r03_pmc_hbm_traffic.txt (the instance <9, 9, true, 2, false, 9> with 13 chained segments: reads 2 x 15,194,464 KiB + writes 9,118,912 KiB;
 # the reads include the helper waves' L2 warm-up touches).  PMC counters cannot be read from inside the timed run, so this is the
 # profile's number for the same kernel and workload, not a value measured in this run.
-PMC_TRAFFIC_C3_BYTES = 3.87e10
+PMC_TRAFFIC_C3_BYTES = 4.05e10
 # the same workload with 5 % of Y missing (AQ_BENCH_NA=0.05: the MASK instance of the look-ahead kernel, which streams the
 # traits' own Gram blocks, 98 GB per sweep): profiles/r03_pmc_hbm_traffic_c3_na5.txt (2 x 64,915,347 KiB + 8,789,477 KiB)
 PMC_TRAFFIC_C3_NA5_BYTES = 1.42e11
