@@ -581,7 +581,10 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
 #ifdef AQ_DIAG_TIME
               const bool x9_ok = s->TT == 2 && NT >= 8 && NT2 == NT && e3 && atoi(e3) == 9;
 #else
-              const bool x9_ok = s->TT == 2 && NT >= 8 && NT2 == NT && (!e3 || atoi(e3) == 9);
+              // (by default from NT = 9 on: 8 / 8 / 9 -- n around 900 -- loses to 9 / 8 / 6, 8.68 against 8.42 us per phase; measured per
+              // geometry in profiles/r03_nt9_stagger.txt: a phase takes max(matrix SIMDs, SIMD 3) with SIMD 3 at 7.6 - 7.7 us for three or
+              // six tiles and 8.7 for nine, the matrix SIMDs at 7.6 / 7.7 / 8.4 / 8.4 / 8.9 / 9.3 / 9.7 / 10.3 us for (8,7) ... (11,11))
+              const bool x9_ok = s->TT == 2 && NT2 == NT && (e3 ? (NT >= 8 && atoi(e3) == 9) : NT >= 9);
 #endif
               for (int x9 = 0; x9 <= (x9_ok ? 1 : 0); x9++) {
                 int nt3 = x9 ? 9 : aq_la_nt3(NT, NT2, s->TT);
@@ -658,7 +661,8 @@ extern "C" int aq_vb_create(const aq_vb_problem *pr, aq_vb_handle *out) {
         // critical cycle: the unsplit MASK instances (single cross-block buffer; C3 + 5 % NA 49.9 -> 48.6 ms on one box, 48.4 -> 47.4
         // on another; the split C5 shard 241.1 -> 242.0, complete Y the same within noise: profiles/r03_hprio_na.txt)
         if (s->la_mask && s->laC <= 1) s->la_hprio = 1;
-        if (s->TT == 2 && s->NT3x == 9) s->la_hprio = 1;   // nine tiles on the recurrence wave: see fit()
+        // six or nine tiles on the recurrence wave of a two-tile workgroup: see fit() (n = 800, geometry 8 / 7 / 6: 33.5 -> 29.6 ms)
+        if (s->TT == 2 && s->NT >= 8 && (s->NT3x == 9 || (s->NT3x < 0 && s->NT2 == s->NT - 1))) s->la_hprio = 1;
         if (const char *e = aq_env(s, "AQ_MPRIO")) s->la_mprio = atoi(e) != 0;
         if (const char *e = aq_env(s, "AQ_HPRIO")) s->la_hprio = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;
         s->la_nt3_pinned = aq_env(s, "AQ_NT3") != nullptr;
