@@ -175,9 +175,10 @@ def test_recurrence_wave_tile_counts_match_oracle(tt, nt3, chain, monkeypatch):
 
 
 @pytest.mark.parametrize("tt", [1, 2])
-@pytest.mark.parametrize("n", [20, 100, 200, 330, 512, 600, 768, 860, 1024, 1040])
+@pytest.mark.parametrize("n", [20, 100, 200, 330, 512, 600, 768, 860, 912, 1000, 1024, 1040])
 def test_look_ahead_kernel_every_tile_count_matches_oracle(n, tt, monkeypatch):
-    """Residual-tile geometries NT/NT2 = 1/1 ... 11/11 of the look-ahead kernel (n = 1040: 65 of the 66 tiles one workgroup
+    """Residual-tile geometries NT/NT2 = 1/1 ... 11/11 of the look-ahead kernel as the host picks them (two tiles per workgroup: 9 / 8 / 6 at
+    n = 860 and 912, 9 / 9 / 9 at 1000, 10 / 10 / 9 at 1024 and 1040, all with the helper wave at raised priority; n = 1040: 65 of the 66 tiles one workgroup
     holds; beyond n = 1056 the sample axis is split over several workgroups, tests/test_gpu_sharded.py), one and two trait
     tiles per workgroup, 12 sweeps each incl. the ladder and two ELBO evaluations."""
     monkeypatch.setenv("AQ_TT", str(tt))
