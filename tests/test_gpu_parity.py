@@ -138,11 +138,12 @@ def test_vb_padding_edges():
 @pytest.mark.parametrize("chain", [0, 5])
 @pytest.mark.parametrize("shape", [(1000, 208, 40), (1008, 130, 17)])
 def test_bench_kernel_instance_matches_oracle(shape, chain, tt, stagger, monkeypatch):
-    """The instances bench.py measures (n = 1000 -> 63 residual tiles): aq_core_sweep_la_kernel<10,9,*,2> -- two trait tiles
-    per workgroup, 10 tiles on waves 0-2, 9 on waves 4-6 and 6 on the recurrence wave; C3 runs this one (q = 40 pads to 4
-    tiles, the last one all padding; q = 17 to 2 tiles, the second one partly) -- and <11,10,*,1> (one tile per workgroup: the
-    trait shards of a multi-GPU run), SIMD partners in step and staggered, plain launch and 5 chained SNP segments, against
-    the oracle over a whole annealed run."""
+    """The instances bench.py measures (n = 1000 -> 63 residual tiles): with two trait tiles per workgroup the host's geometry --
+    since the end of round 3 aq_core_sweep_la_kernel<9,9,*,2,false,9>: 9 tiles on every matrix wave and 9 on the recurrence wave,
+    helper wave at raised priority; C3 runs this one (q = 40 pads to 4 tiles, the last one all padding; q = 17 to 2 tiles, the
+    second one partly); <10,9,*,2> and <10,10,*,2> through test_recurrence_wave_tile_counts_match_oracle below -- and the one-tile
+    instance (the trait shards of a multi-GPU run), SIMD partners in step and staggered, plain launch and 5 chained SNP
+    segments (the bench's 13: tests/test_gpu_bigp.py), against the oracle over a whole annealed run."""
     monkeypatch.setenv("AQ_CHAIN", str(chain))
     monkeypatch.setenv("AQ_TT", str(tt))
     monkeypatch.setenv("AQ_STAGGER", str(stagger))
